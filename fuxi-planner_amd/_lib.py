@@ -1,0 +1,79 @@
+"""ctypes binding of libfxjps.so (include/fxjps.h).  No CPU fallback: if the HIP
+library cannot be loaded, or no MI355X is visible, every entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+# FXJPS_LIB: bring-up override (e.g. the traced build); the package default is the in-tree library
+LIB_PATH = os.environ.get("FXJPS_LIB") or os.path.join(_HERE, "libfxjps.so")
+
+OK = 0
+E_ARG, E_NODEV, E_HIP, E_NOGRID, E_NOMEM, E_COMM = -1, -2, -3, -4, -5, -6
+Q_NOPATH, Q_PATH_TOO_LONG, Q_BAD_START, Q_CAPACITY = 0, -1, -2, -3
+BACKEND_HIP = 1
+
+# every symbol include/fxjps.h declares (tests check the .so exports all of them)
+SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
+           "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_update_cells", "fxjps_plan_batch",
+           "fxjps_plan_batch_csr", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_debug_read_nbmask")
+
+
+class Timing(C.Structure):
+    _fields_ = [("search_kernel_ms", C.c_double), ("total_ms", C.c_double), ("search_launches", C.c_int64),
+                ("retried", C.c_int64), ("pops", C.c_int64), ("pushes", C.c_int64)]
+
+
+class FxjpsError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "fxjps error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libfxjps.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FxjpsError(E_NODEV, "%s is missing: build it with `make -C %s` (hipcc, gfx950); "
+                         "there is no CPU fallback" % (LIB_PATH, _HERE))
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    p_i32 = C.POINTER(C.c_int32)
+    p_i64 = C.POINTER(C.c_int64)
+    p_u8 = C.POINTER(C.c_uint8)
+    p_f64 = C.POINTER(C.c_double)
+    L.fxjps_version.restype = C.c_int
+    L.fxjps_device_count.restype = C.c_int
+    L.fxjps_create.restype = C.c_int
+    L.fxjps_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.fxjps_destroy.restype = None
+    L.fxjps_destroy.argtypes = [vp]
+    L.fxjps_last_error.restype = C.c_char_p
+    L.fxjps_last_error.argtypes = [vp]
+    L.fxjps_set_grid.restype = C.c_int
+    L.fxjps_set_grid.argtypes = [vp, p_u8, C.c_int32, C.c_int32]
+    L.fxjps_set_grid_device.restype = C.c_int
+    L.fxjps_set_grid_device.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.fxjps_update_cells.restype = C.c_int
+    L.fxjps_update_cells.argtypes = [vp, p_i32, p_u8, C.c_int64]
+    L.fxjps_plan_batch.restype = C.c_int
+    L.fxjps_plan_batch.argtypes = [vp, p_i32, p_i32, C.c_int64, C.c_int32, C.c_int32, p_i32, p_i32, p_f64, p_f64]
+    L.fxjps_plan_batch_csr.restype = C.c_int
+    L.fxjps_plan_batch_csr.argtypes = [vp, p_i32, p_i32, C.c_int64, C.c_int32, C.c_int32, p_i64, p_i32,
+                                       C.c_int64, p_i32, p_f64, p_f64]
+    L.fxjps_last_timing.restype = C.c_int
+    L.fxjps_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.fxjps_selftest_sqrt.restype = C.c_int
+    L.fxjps_selftest_sqrt.argtypes = [vp, C.c_uint32, C.c_uint32, p_f64]
+    L.fxjps_debug_read_nbmask.restype = C.c_int
+    L.fxjps_debug_read_nbmask.argtypes = [vp, p_u8]
+    _lib = L
+    return L
+
+
+def ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))

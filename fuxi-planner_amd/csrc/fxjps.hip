@@ -1,0 +1,753 @@
+// fxjps.hip -- host side of libfxjps.so: the C ABI of include/fxjps.h on top of
+// the HIP kernels in fxjps_kernels.hip.inc.  gfx950 only; no CPU fallback: if
+// there is no HIP device every entry point fails with FXJPS_E_NODEV.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see Makefile).
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fxjps.h"
+#include "fxjps_kernels.hip.inc"
+
+namespace {
+
+using fx::FarEnt;
+using fx::GridDev;
+using fx::SearchArgs;
+using fx::TEnt;
+
+std::string g_create_error;
+
+// FXJPS_DEBUG=1 in the environment: progress lines on stderr (bring-up aid)
+bool dbg_on() {
+    static int on = -1;
+    if (on < 0) on = getenv("FXJPS_DEBUG") ? 1 : 0;
+    return on == 1;
+}
+#define DBG(...)                          \
+    do {                                  \
+        if (dbg_on()) {                   \
+            fprintf(stderr, "[fxjps] ");  \
+            fprintf(stderr, __VA_ARGS__); \
+            fprintf(stderr, "\n");        \
+            fflush(stderr);               \
+        }                                 \
+    } while (0)
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+struct DBuf {  // grow-only device buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct HBuf {  // grow-only pinned host buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ScratchCfg {
+    uint32_t nwaves = 0;
+    uint32_t log2_buckets = 0;
+    uint32_t far_cap = 0;
+};
+
+struct DevCtx {
+    int dev = -1;
+    int n_cu = 256;
+    size_t mem_total = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // grid
+    int W = 0, H = 0, PW = 0, PH = 0, NS = 0, RW = 0, CW = 0;
+    DBuf<uint8_t> occ, nb8;
+    DBuf<uint64_t> occR, stopYp, stopYm, occC, stopXp, stopXm;
+    // search scratch (two pools: the regular one and the large retry one)
+    DBuf<TEnt> tables[2];
+    DBuf<FarEnt> far[2];
+    ScratchCfg cfg[2];
+    bool pool_clean[2] = {false, false};
+    // batch buffers
+    DBuf<int32_t> d_starts, d_goals, d_len, d_cells;
+    DBuf<double> d_cost;
+    DBuf<uint32_t> d_path, d_order;
+    DBuf<long long> d_offsets;
+    DBuf<unsigned int> d_next;
+    DBuf<unsigned long long> d_counters;
+    DBuf<int32_t> d_upd_xy;
+    DBuf<uint8_t> d_upd_val;
+    HBuf<int32_t> h_len, h_cells;
+    HBuf<double> h_cost;
+    HBuf<long long> h_offsets;
+    HBuf<unsigned long long> h_counters;
+    // shard of the current batch
+    int64_t q0 = 0, nq = 0;
+    double kernel_ms = 0;
+    int64_t launches = 0, retried = 0;
+    unsigned int* trace = nullptr;  // FXJPS_TRACE builds only
+};
+
+}  // namespace
+
+struct fxjps {
+    std::vector<DevCtx> devs;
+    std::string err;
+    bool have_grid = false;
+    fxjps_timing_t timing{};
+    // RCCL (only for n_dev > 1), resolved with dlopen so that a single-GPU
+    // deployment does not need librccl at load time
+    void* rccl = nullptr;
+    std::vector<void*> comms;
+};
+
+namespace {
+
+int fail(fxjps* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h)
+        h->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail(h, e__ == hipErrorOutOfMemory ? FXJPS_E_NOMEM : FXJPS_E_HIP, "%s: %s (%s:%d)", \
+                        #call, hipGetErrorString(e__), __FILE__, __LINE__);                      \
+    } while (0)
+
+GridDev grid_of(const DevCtx& d) {
+    GridDev G;
+    G.nb8 = d.nb8.p;
+    G.occR = d.occR.p;
+    G.stopYp = d.stopYp.p;
+    G.stopYm = d.stopYm.p;
+    G.occC = d.occC.p;
+    G.stopXp = d.stopXp.p;
+    G.stopXm = d.stopXm.p;
+    G.comp = nullptr;
+    G.W = d.W;
+    G.H = d.H;
+    G.PW = d.PW;
+    G.PH = d.PH;
+    G.NS = d.NS;
+    G.RW = d.RW;
+    G.CW = d.CW;
+    return G;
+}
+
+// (re)build nb8 + the six scan bitmaps from d.occ
+int derive_maps(fxjps* h, DevCtx& d) {
+    HIPCHK(h, hipSetDevice(d.dev));
+    const long long nrw = (long long)d.PW * d.RW, ncw = (long long)d.PH * d.CW;
+    hipLaunchKernelGGL(fx::k_derive_rows, dim3((unsigned)((nrw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, d.W,
+                       d.H, d.PW, d.PH, d.NS, d.RW, d.nb8.p, d.occR.p, d.stopYp.p, d.stopYm.p);
+    hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, d.W,
+                       d.H, d.PW, d.PH, d.NS, d.CW, d.nb8.p, d.occC.p, d.stopXp.p, d.stopXm.p);
+    HIPCHK(h, hipGetLastError());
+    return FXJPS_OK;
+}
+
+int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
+    HIPCHK(h, hipSetDevice(d.dev));
+    d.W = W;
+    d.H = H;
+    d.PW = W + 2;
+    d.PH = H + 2;
+    d.NS = (d.PH + 63) & ~63;
+    d.RW = (d.PH + 63) / 64;
+    d.CW = (d.PW + 63) / 64;
+    HIPCHK(h, d.occ.ensure((size_t)W * H));
+    HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
+    const size_t nr = (size_t)d.PW * d.RW, nc = (size_t)d.PH * d.CW;
+    HIPCHK(h, d.occR.ensure(nr));
+    HIPCHK(h, d.stopYp.ensure(nr));
+    HIPCHK(h, d.stopYm.ensure(nr));
+    HIPCHK(h, d.occC.ensure(nc));
+    HIPCHK(h, d.stopXp.ensure(nc));
+    HIPCHK(h, d.stopXm.ensure(nc));
+    return FXJPS_OK;
+}
+
+uint32_t ceil_log2(uint64_t v) {
+    uint32_t l = 0;
+    while ((1ull << l) < v) l++;
+    return l;
+}
+
+// Size the per-wavefront scratch.  pool 0: many wavefronts, tables sized for the
+// typical query; pool 1: few wavefronts, tables that cannot overflow.
+int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
+    const uint64_t cells = (uint64_t)d.W * d.H;
+    ScratchCfg c;
+    if (pool == 0) {
+        // typical query touches ~4 % of the cells (37 k pushes on 1 Mi cells)
+        uint32_t l2e = ceil_log2(std::max<uint64_t>(cells / 16, 1));  // entries
+        l2e = std::min(std::max(l2e, 12u), 21u);
+        c.log2_buckets = l2e - 3;
+        c.far_cap = std::max<uint32_t>(1024u, (8u << c.log2_buckets) / 4);
+        c.nwaves = want_waves;
+    } else {
+        const uint32_t l2e = std::max(ceil_log2(cells * 2 + 64), 12u);
+        c.log2_buckets = l2e - 3;
+        c.far_cap = (uint32_t)std::min<uint64_t>(cells * 2 + 1024, 0x7FFFFFFFull);
+        c.nwaves = want_waves;
+    }
+    // memory budget: at most 60 % of the device for one pool
+    const size_t per_wave = ((size_t)8 << c.log2_buckets) * sizeof(TEnt) + (size_t)c.far_cap * sizeof(FarEnt);
+    const size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
+    uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
+    maxw &= ~3u;
+    if (maxw < 4) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
+    c.nwaves = std::max(4u, std::min(c.nwaves & ~3u, maxw));
+    ScratchCfg& cur = d.cfg[pool];
+    if (cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves && d.pool_clean[pool])
+        return FXJPS_OK;
+    if (!(cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves)) {
+        HIPCHK(h, d.tables[pool].ensure((size_t)c.nwaves * ((size_t)8 << c.log2_buckets)));
+        HIPCHK(h, d.far[pool].ensure((size_t)c.nwaves * c.far_cap));
+        cur = c;
+    }
+    // tables must start all-empty (key 0xFFFFFFFF); wavefronts leave them clean after each query
+    HIPCHK(h, hipMemsetAsync(d.tables[pool].p, 0xFF, (size_t)cur.nwaves * ((size_t)8 << cur.log2_buckets) * sizeof(TEnt),
+                             d.stream));
+    d.pool_clean[pool] = true;
+    return FXJPS_OK;
+}
+
+int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32_t nrun, int hchoice, int max_len) {
+    const ScratchCfg& c = d.cfg[pool];
+    SearchArgs A;
+    A.G = grid_of(d);
+    A.starts = d.d_starts.p;
+    A.goals = d.d_goals.p;
+    A.order = d_order;
+    A.nrun = nrun;
+    A.max_len = max_len;
+    A.out_path = d.d_path.p;
+    A.out_len = d.d_len.p;
+    A.out_cost = d.d_cost.p;
+    A.out_counters = d.d_counters.p;
+    A.tables = d.tables[pool].p;
+    A.far = d.far[pool].p;
+    A.log2_buckets = c.log2_buckets;
+    A.far_cap = c.far_cap;
+    A.next = d.d_next.p;
+    A.max_pops = 64ull * (unsigned long long)d.W * d.H + 4096ull;
+    A.trace = nullptr;
+#ifdef FXJPS_TRACE
+    if (!d.trace) {
+        HIPCHK(h, hipHostMalloc((void**)&d.trace, (size_t)(1u << 20) * sizeof(unsigned int),
+                                hipHostMallocCoherent | hipHostMallocMapped));
+        memset(d.trace, 0, (size_t)(1u << 20) * sizeof(unsigned int));
+    }
+    A.trace = d.trace;
+#endif
+    HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
+    uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
+    waves = std::max<uint32_t>(4u, (waves + 3u) & ~3u);
+    waves = std::min<uint32_t>(waves, c.nwaves);
+    const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
+    DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
+    HIPCHK(h, hipEventRecord(d.ev0, d.stream));
+    if (hchoice == 1)
+        hipLaunchKernelGGL(fx::k_search<1>, grid, block, 0, d.stream, A);
+    else
+        hipLaunchKernelGGL(fx::k_search<2>, grid, block, 0, d.stream, A);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(d.ev1, d.stream));
+    d.launches++;
+    return FXJPS_OK;
+}
+
+// Runs the shard [q0, q0+nq) of the batch on device d up to the point where
+// len/cost/offsets are in pinned host memory and the CSR cells are packed on
+// the device.
+int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, int hchoice, int max_len) {
+    HIPCHK(h, hipSetDevice(d.dev));
+    const int64_t nq = d.nq;
+    d.kernel_ms = 0;
+    d.launches = 0;
+    d.retried = 0;
+    if (nq == 0) return FXJPS_OK;
+    HIPCHK(h, d.d_starts.ensure((size_t)nq * 2));
+    HIPCHK(h, d.d_goals.ensure((size_t)nq * 2));
+    HIPCHK(h, d.d_len.ensure((size_t)nq));
+    HIPCHK(h, d.d_cost.ensure((size_t)nq));
+    HIPCHK(h, d.d_path.ensure((size_t)nq * max_len));
+    HIPCHK(h, d.d_offsets.ensure((size_t)nq + 1));
+    HIPCHK(h, d.d_next.ensure(4));
+    HIPCHK(h, d.d_counters.ensure(4));
+    HIPCHK(h, d.h_len.ensure((size_t)nq));
+    HIPCHK(h, d.h_cost.ensure((size_t)nq));
+    HIPCHK(h, d.h_offsets.ensure((size_t)nq + 1));
+    HIPCHK(h, d.h_counters.ensure(4));
+    HIPCHK(h, hipMemcpyAsync(d.d_starts.p, starts + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+    HIPCHK(h, hipMemcpyAsync(d.d_goals.p, goals + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 4 * sizeof(unsigned long long), d.stream));
+    const uint32_t full = (uint32_t)d.n_cu * 32u;
+    DBG("run_shard nq=%lld: inputs queued", (long long)nq);
+    int rc = ensure_pool(h, d, 0, (uint32_t)std::min<int64_t>(full, (nq + 3) & ~3ll));
+    if (rc) return rc;
+    DBG("pool ready");
+    rc = launch_search(h, d, 0, nullptr, (uint32_t)nq, hchoice, max_len);
+    if (rc) return rc;
+    return FXJPS_OK;
+}
+
+// Second half: wait for the search, retry overflowed queries with the large
+// pool, pack to CSR, copy len/cost/offsets back.
+int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
+    HIPCHK(h, hipSetDevice(d.dev));
+    const int64_t nq = d.nq;
+    if (nq == 0) return FXJPS_OK;
+    HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+    DBG("waiting for the search kernel");
+    HIPCHK(h, hipStreamSynchronize(d.stream));
+    DBG("search kernel done");
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+    d.kernel_ms += ms;
+    std::vector<uint32_t> redo;
+    for (int64_t i = 0; i < nq; i++)
+        if (d.h_len.p[i] <= fx::QI_TABLE_FULL) redo.push_back((uint32_t)i);
+    if (!redo.empty()) {
+        d.retried = (int64_t)redo.size();
+        int rc = ensure_pool(h, d, 1, (uint32_t)std::min<size_t>(256, (redo.size() + 3) & ~(size_t)3));
+        if (rc) return rc;
+        HIPCHK(h, d.d_order.ensure(redo.size()));
+        HIPCHK(h, hipMemcpyAsync(d.d_order.p, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        rc = launch_search(h, d, 1, d.d_order.p, (uint32_t)redo.size(), hchoice, max_len);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
+        HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+        d.kernel_ms += ms;
+    }
+    DBG("kernel %.3f ms, %zu to redo; scan", d.kernel_ms, redo.size());
+    hipLaunchKernelGGL(fx::k_scan_len, dim3(1), dim3(1024), 0, d.stream, d.d_len.p, (long long)nq, d.d_offsets.p);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(d.h_offsets.p, d.d_offsets.p, ((size_t)nq + 1) * sizeof(long long), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipMemcpyAsync(d.h_cost.p, d.d_cost.p, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
+    const long long total = d.h_offsets.p[nq];
+    DBG("scan done, %lld cells", total);
+    if (total > 0) {
+        HIPCHK(h, d.d_cells.ensure((size_t)total * 2));
+        HIPCHK(h, d.h_cells.ensure((size_t)total * 2));
+        hipLaunchKernelGGL(fx::k_gather_paths, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, d.stream, d.d_path.p,
+                           d.d_len.p, d.d_offsets.p, (long long)nq, max_len, d.d_cells.p, total);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(d.h_cells.p, d.d_cells.p, (size_t)total * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
+    }
+    DBG("gather done");
+    // internal codes must not leak
+    for (int64_t i = 0; i < nq; i++)
+        if (d.h_len.p[i] <= fx::QI_TABLE_FULL) d.h_len.p[i] = FXJPS_Q_CAPACITY;
+    return FXJPS_OK;
+}
+
+int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq, int hchoice, int max_len) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_plan_batch before fxjps_set_grid");
+    if (nq < 0 || (nq > 0 && (!starts || !goals))) return fail(h, FXJPS_E_ARG, "bad query arrays");
+    if (hchoice != 1 && hchoice != 2)
+        return fail(h, FXJPS_E_ARG, "hchoice must be 1 or 2 (the reference raises TypeError, jps1.py:188)");
+    if (max_len < 1 || max_len > (1 << 20)) return fail(h, FXJPS_E_ARG, "max_path_len out of range");
+    if (nq > 0x7FFFFFF0ll) return fail(h, FXJPS_E_ARG, "too many queries in one batch");
+    const int nd = (int)h->devs.size();
+    for (int r = 0; r < nd; r++) {  // contiguous shards: SURVEY 8(e)
+        h->devs[r].q0 = nq * r / nd;
+        h->devs[r].nq = nq * (r + 1) / nd - h->devs[r].q0;
+    }
+    for (int r = 0; r < nd; r++) {
+        int rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
+        if (rc) return rc;
+    }
+    for (int r = 0; r < nd; r++) {
+        int rc = finish_shard(h, h->devs[r], hchoice, max_len);
+        if (rc) return rc;
+    }
+    fxjps_timing_t& T = h->timing;
+    T.search_kernel_ms = 0;
+    T.search_launches = 0;
+    T.retried = 0;
+    T.pops = 0;
+    T.pushes = 0;
+    for (auto& d : h->devs) {
+        T.search_kernel_ms = std::max(T.search_kernel_ms, d.kernel_ms);
+        T.search_launches += d.launches;
+        T.retried += d.retried;
+        if (d.nq > 0) {
+            T.pops += (int64_t)d.h_counters.p[0];
+            T.pushes += (int64_t)d.h_counters.p[1];
+        }
+    }
+    return FXJPS_OK;
+}
+
+typedef int (*nccl_init_all_t)(void**, int, const int*);
+typedef int (*nccl_bcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_group_t)(void);
+typedef int (*nccl_destroy_t)(void*);
+
+int broadcast_grid(fxjps* h, int W, int H) {
+    const int nd = (int)h->devs.size();
+    if (nd == 1) return FXJPS_OK;
+    if (!h->rccl) {
+        h->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h->rccl) h->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h->rccl) return fail(h, FXJPS_E_COMM, "cannot load librccl.so: %s", dlerror());
+        auto init_all = (nccl_init_all_t)dlsym(h->rccl, "ncclCommInitAll");
+        if (!init_all) return fail(h, FXJPS_E_COMM, "ncclCommInitAll not found");
+        std::vector<int> ids;
+        for (auto& d : h->devs) ids.push_back(d.dev);
+        h->comms.assign(nd, nullptr);
+        if (init_all(h->comms.data(), nd, ids.data()) != 0) return fail(h, FXJPS_E_COMM, "ncclCommInitAll failed");
+    }
+    auto bcast = (nccl_bcast_t)dlsym(h->rccl, "ncclBroadcast");
+    auto gstart = (nccl_group_t)dlsym(h->rccl, "ncclGroupStart");
+    auto gend = (nccl_group_t)dlsym(h->rccl, "ncclGroupEnd");
+    if (!bcast || !gstart || !gend) return fail(h, FXJPS_E_COMM, "RCCL symbols missing");
+    // one broadcast of W*H bytes, root = first device, over xGMI; no other collective exists on this path
+    gstart();
+    for (int r = 0; r < nd; r++) {
+        DevCtx& d = h->devs[r];
+        (void)hipSetDevice(d.dev);
+        if (bcast(d.occ.p, d.occ.p, (size_t)W * H, /*ncclUint8*/ 1, 0, h->comms[r], d.stream) != 0) {
+            gend();
+            return fail(h, FXJPS_E_COMM, "ncclBroadcast failed on device %d", d.dev);
+        }
+    }
+    if (gend() != 0) return fail(h, FXJPS_E_COMM, "ncclGroupEnd failed");
+    return FXJPS_OK;
+}
+
+int finish_set_grid(fxjps* h, int W, int H) {
+    int rc = broadcast_grid(h, W, H);
+    if (rc) return rc;
+    for (auto& d : h->devs) {
+        rc = derive_maps(h, d);
+        if (rc) return rc;
+    }
+    for (auto& d : h->devs) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
+    }
+    h->have_grid = true;
+    return FXJPS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fxjps_version(void) { return 100; }
+
+int fxjps_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return FXJPS_E_NODEV;
+    return n;
+}
+
+int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
+    if (!out) return fail(nullptr, FXJPS_E_ARG, "out == NULL");
+    *out = nullptr;
+    if (backend != FXJPS_BACKEND_HIP)
+        return fail(nullptr, FXJPS_E_ARG, "backend %d: only FXJPS_BACKEND_HIP exists (no CPU fallback)", backend);
+    int navail = 0;
+    if (hipGetDeviceCount(&navail) != hipSuccess || navail <= 0)
+        return fail(nullptr, FXJPS_E_NODEV, "no HIP device visible: the planner needs an MI355X (no CPU fallback)");
+    if (n_dev < 1 || n_dev > navail) return fail(nullptr, FXJPS_E_ARG, "n_dev=%d but %d device(s) visible", n_dev, navail);
+    fxjps* h = new (std::nothrow) fxjps();
+    if (!h) return fail(nullptr, FXJPS_E_NOMEM, "out of host memory");
+    h->devs.resize(n_dev);
+    for (int r = 0; r < n_dev; r++) {
+        DevCtx& d = h->devs[r];
+        d.dev = device_ids ? device_ids[r] : r;
+        hipDeviceProp_t prop;
+        hipError_t e = hipSetDevice(d.dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d.dev);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&d.ev0);
+        if (e == hipSuccess) e = hipEventCreate(&d.ev1);
+        if (e != hipSuccess) {
+            int rc = fail(nullptr, FXJPS_E_HIP, "device %d: %s", d.dev, hipGetErrorString(e));
+            fxjps_destroy(h);
+            return rc;
+        }
+        d.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        d.mem_total = prop.totalGlobalMem;
+    }
+    *out = h;
+    return FXJPS_OK;
+}
+
+void fxjps_destroy(fxjps_t* h) {
+    if (!h) return;
+    if (h->rccl) {
+        auto destroy = (nccl_destroy_t)dlsym(h->rccl, "ncclCommDestroy");
+        if (destroy)
+            for (void* c : h->comms)
+                if (c) destroy(c);
+    }
+    for (auto& d : h->devs) {
+        if (d.dev < 0) continue;
+        (void)hipSetDevice(d.dev);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        d.occ.release();
+        d.nb8.release();
+        d.occR.release();
+        d.stopYp.release();
+        d.stopYm.release();
+        d.occC.release();
+        d.stopXp.release();
+        d.stopXm.release();
+        for (int p = 0; p < 2; p++) {
+            d.tables[p].release();
+            d.far[p].release();
+        }
+        d.d_starts.release();
+        d.d_goals.release();
+        d.d_len.release();
+        d.d_cells.release();
+        d.d_cost.release();
+        d.d_path.release();
+        d.d_order.release();
+        d.d_offsets.release();
+        d.d_next.release();
+        d.d_counters.release();
+        d.d_upd_xy.release();
+        d.d_upd_val.release();
+        d.h_len.release();
+        d.h_cells.release();
+        d.h_cost.release();
+        d.h_offsets.release();
+        d.h_counters.release();
+        if (d.ev0) (void)hipEventDestroy(d.ev0);
+        if (d.ev1) (void)hipEventDestroy(d.ev1);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete h;
+}
+
+const char* fxjps_last_error(fxjps_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
+    if (!h) return FXJPS_E_ARG;
+    if (!occ || W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
+    h->have_grid = false;
+    for (auto& d : h->devs) {
+        int rc = alloc_grid(h, d, W, H);
+        if (rc) return rc;
+        d.pool_clean[0] = d.pool_clean[1] = false;
+        d.cfg[0] = ScratchCfg();
+        d.cfg[1] = ScratchCfg();
+    }
+    DevCtx& d0 = h->devs[0];
+    HIPCHK(h, hipSetDevice(d0.dev));
+    HIPCHK(h, hipMemcpyAsync(d0.occ.p, occ, (size_t)W * H, hipMemcpyHostToDevice, d0.stream));
+    HIPCHK(h, hipStreamSynchronize(d0.stream));
+    return finish_set_grid(h, W, H);
+}
+
+int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
+    if (!h) return FXJPS_E_ARG;
+    if (!d_occ || W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
+    h->have_grid = false;
+    for (auto& d : h->devs) {
+        int rc = alloc_grid(h, d, W, H);
+        if (rc) return rc;
+        d.pool_clean[0] = d.pool_clean[1] = false;
+        d.cfg[0] = ScratchCfg();
+        d.cfg[1] = ScratchCfg();
+    }
+    DevCtx& d0 = h->devs[0];
+    HIPCHK(h, hipSetDevice(d0.dev));
+    HIPCHK(h, hipMemcpyAsync(d0.occ.p, d_occ, (size_t)W * H, hipMemcpyDeviceToDevice, d0.stream));
+    HIPCHK(h, hipStreamSynchronize(d0.stream));
+    return finish_set_grid(h, W, H);
+}
+
+int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_update_cells before fxjps_set_grid");
+    if (n < 0 || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
+    if (n == 0) return FXJPS_OK;
+    // every device applies the same (small) update list; cheaper than re-broadcasting the grid
+    for (auto& d : h->devs) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, d.d_upd_xy.ensure((size_t)n * 2));
+        HIPCHK(h, d.d_upd_val.ensure((size_t)n));
+        HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, val, (size_t)n, hipMemcpyHostToDevice, d.stream));
+        hipLaunchKernelGGL(fx::k_update_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.occ.p,
+                           d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p, (long long)n);
+        HIPCHK(h, hipGetLastError());
+        int rc = derive_maps(h, d);
+        if (rc) return rc;
+    }
+    for (auto& d : h->devs) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
+    }
+    return FXJPS_OK;
+}
+
+int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq,
+                         int32_t hchoice, int32_t max_path_len, int64_t* out_offsets, int32_t* out_cells_xy,
+                         int64_t cells_capacity, int32_t* out_len, double* out_cost, double* out_seconds_total) {
+    const double t0 = now_s();
+    if (!h) return FXJPS_E_ARG;
+    if (nq > 0 && (!out_offsets || !out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
+    int rc = plan_core(h, starts_xy, goals_xy, nq, hchoice, max_path_len);
+    if (rc) return rc;
+    int64_t base = 0;
+    bool fits = true;
+    for (auto& d : h->devs) {
+        if (d.nq == 0) continue;
+        memcpy(out_len + d.q0, d.h_len.p, (size_t)d.nq * sizeof(int32_t));
+        memcpy(out_cost + d.q0, d.h_cost.p, (size_t)d.nq * sizeof(double));
+        for (int64_t i = 0; i < d.nq; i++) out_offsets[d.q0 + i] = base + d.h_offsets.p[i];
+        const int64_t total = d.h_offsets.p[d.nq];
+        if (base + total > cells_capacity || (total > 0 && !out_cells_xy))
+            fits = false;
+        else if (total > 0)
+            memcpy(out_cells_xy + 2 * base, d.h_cells.p, (size_t)total * 2 * sizeof(int32_t));
+        base += total;
+    }
+    if (out_offsets) out_offsets[nq] = base;
+    h->timing.total_ms = (now_s() - t0) * 1e3;
+    if (out_seconds_total) *out_seconds_total = now_s() - t0;
+    if (!fits) return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, batch needs %lld", (long long)cells_capacity, (long long)base);
+    return FXJPS_OK;
+}
+
+int fxjps_plan_batch(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq, int32_t hchoice,
+                     int32_t max_path_len, int32_t* out_cells_xy, int32_t* out_len, double* out_cost,
+                     double* out_seconds_total) {
+    const double t0 = now_s();
+    if (!h) return FXJPS_E_ARG;
+    if (nq > 0 && (!out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
+    int rc = plan_core(h, starts_xy, goals_xy, nq, hchoice, max_path_len);
+    if (rc) return rc;
+    for (auto& d : h->devs) {
+        if (d.nq == 0) continue;
+        memcpy(out_len + d.q0, d.h_len.p, (size_t)d.nq * sizeof(int32_t));
+        memcpy(out_cost + d.q0, d.h_cost.p, (size_t)d.nq * sizeof(double));
+        if (out_cells_xy)
+            for (int64_t i = 0; i < d.nq; i++) {
+                const int32_t n = d.h_len.p[i];
+                if (n > 0)
+                    memcpy(out_cells_xy + (size_t)(d.q0 + i) * max_path_len * 2, d.h_cells.p + 2 * d.h_offsets.p[i],
+                           (size_t)n * 2 * sizeof(int32_t));
+            }
+    }
+    h->timing.total_ms = (now_s() - t0) * 1e3;
+    if (out_seconds_total) *out_seconds_total = now_s() - t0;
+    return FXJPS_OK;
+}
+
+int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out) {
+    if (!h || !out) return FXJPS_E_ARG;
+    *out = h->timing;
+    return FXJPS_OK;
+}
+
+int fxjps_selftest_sqrt(fxjps_t* h, uint32_t n0, uint32_t n1, double* out) {
+    if (!h || !out || n1 < n0) return FXJPS_E_ARG;
+    if (n1 == n0) return FXJPS_OK;
+    DevCtx& d = h->devs[0];
+    HIPCHK(h, hipSetDevice(d.dev));
+    const size_t n = (size_t)(n1 - n0);
+    double* buf = nullptr;
+    HIPCHK(h, hipMalloc((void**)&buf, n * sizeof(double)));
+    hipLaunchKernelGGL(fx::k_sqrt_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, n0, n1, buf);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, buf, n * sizeof(double), hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(h, FXJPS_E_HIP, "selftest: %s", hipGetErrorString(e));
+    return FXJPS_OK;
+}
+
+#ifdef FXJPS_TRACE
+// bring-up only (libfxjps_trace.so): host pointer to the progress words of device 0
+unsigned int* fxjps_debug_trace_ptr(fxjps_t* h) {
+    if (!h) return nullptr;
+    DevCtx& d = h->devs[0];
+    if (!d.trace) {
+        (void)hipSetDevice(d.dev);
+        if (hipHostMalloc((void**)&d.trace, (size_t)(1u << 20) * sizeof(unsigned int),
+                          hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
+            return nullptr;
+        memset(d.trace, 0, (size_t)(1u << 20) * sizeof(unsigned int));
+    }
+    return d.trace;
+}
+#endif
+
+int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf) {
+    if (!h || !buf) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
+    DevCtx& d = h->devs[0];
+    HIPCHK(h, hipSetDevice(d.dev));
+    HIPCHK(h, hipMemcpy2D(buf, (size_t)d.PH, d.nb8.p, (size_t)d.NS, (size_t)d.PH, (size_t)d.PW, hipMemcpyDeviceToHost));
+    return FXJPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""Host-side planner object: owns one libfxjps handle (one or more MI355X) and
+mirrors the reference's call surface for the grid search.
+
+Reference interface being replaced: jps1.method(matrix, start, goal, hchoice)
+(scripts/jps1.py:183-230), called from scripts/global_planner_st.py:285 and
+scripts/global_planner_ccst.py:477.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FxjpsError
+
+
+def as_occ(matrix):
+    """The reference treats a cell as an obstacle iff it compares equal to 1
+    (jps1.py:20-29); 100, 0.5, -1 ... are free."""
+    return np.ascontiguousarray(np.asarray(matrix) == 1, dtype=np.uint8)
+
+
+class Planner(object):
+    """A resident occupancy grid plus batched (start, goal) planning on the GPU."""
+
+    def __init__(self, devices=None):
+        L = _lib.load()
+        n = L.fxjps_device_count()
+        if n <= 0:
+            raise FxjpsError(_lib.E_NODEV, "no HIP device visible: fuxi-planner_amd has no CPU fallback")
+        if devices is None:
+            devices = [0]
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = L.fxjps_create(_lib.BACKEND_HIP, ids, len(devices), C.byref(h))
+        if rc != 0:
+            raise FxjpsError(rc, (L.fxjps_last_error(None) or b"").decode())
+        self._L = L
+        self._h = h
+        self.devices = list(devices)
+        self.shape = None
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fxjps_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FxjpsError(rc, (self._L.fxjps_last_error(self._h) or b"").decode())
+
+    # -- grid
+    def set_grid(self, matrix):
+        """Upload `matrix` (any 2-D array, matrix[x][y], obstacle iff == 1)."""
+        self.set_grid_occ(as_occ(matrix))
+
+    def set_grid_occ(self, occ):
+        """Upload a uint8 [W][H] occupancy array (non-zero = obstacle)."""
+        occ = np.ascontiguousarray(occ, dtype=np.uint8)
+        if occ.ndim != 2:
+            raise ValueError("grid must be 2-D")
+        W, H = occ.shape
+        self._chk(self._L.fxjps_set_grid(self._h, _lib.ptr(occ, C.c_uint8), W, H))
+        self.shape = (W, H)
+
+    def set_grid_device(self, dev_ptr, W, H):
+        """Adopt a uint8 [W][H] grid that already lives in device memory
+        (e.g. the output of an RCCL broadcast done by the host framework)."""
+        self._chk(self._L.fxjps_set_grid_device(self._h, C.c_void_p(int(dev_ptr)), int(W), int(H)))
+        self.shape = (int(W), int(H))
+
+    def update_cells(self, xy, val):
+        xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
+        if len(val) != len(xy):
+            raise ValueError("xy and val lengths differ")
+        self._chk(self._L.fxjps_update_cells(self._h, _lib.ptr(xy, C.c_int32), _lib.ptr(val, C.c_uint8), len(val)))
+
+    # -- planning
+    def default_max_path_len(self):
+        W, H = self.shape
+        return int(min(W * H + 1, max(256, 4 * max(W, H))))
+
+    def plan_batch(self, starts, goals, hchoice=2, max_path_len=None):
+        """-> (offsets int64[n+1], cells int32[total,2], cost float64[n], status int32[n]).
+
+        status[q] > 0: number of jump points of query q (cells[offsets[q]:offsets[q+1]]),
+        0: no path, < 0: a per-query error code (_lib.Q_*)."""
+        if self.shape is None:
+            raise FxjpsError(_lib.E_NOGRID, "plan_batch before set_grid")
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        goals = np.ascontiguousarray(goals, dtype=np.int32).reshape(-1, 2)
+        if len(starts) != len(goals):
+            raise ValueError("starts and goals lengths differ")
+        if hchoice not in (1, 2):
+            # heuristic() returns None and jps1.py:188/227 then fails on None + float
+            raise TypeError("unsupported operand type(s) for +: 'float' and 'NoneType' (hchoice must be 1 or 2)")
+        n = len(starts)
+        auto = max_path_len is None
+        mpl = self.default_max_path_len() if auto else int(max_path_len)
+        limit = self.shape[0] * self.shape[1] + 1
+        while True:
+            offsets = np.zeros(n + 1, dtype=np.int64)
+            status = np.zeros(n, dtype=np.int32)
+            cost = np.zeros(n, dtype=np.float64)
+            cap = max(1024, n * 64)
+            secs = C.c_double(0.0)
+            while True:
+                cells = np.empty((cap, 2), dtype=np.int32)
+                rc = self._L.fxjps_plan_batch_csr(self._h, _lib.ptr(starts, C.c_int32), _lib.ptr(goals, C.c_int32), n,
+                                                  int(hchoice), mpl, _lib.ptr(offsets, C.c_int64),
+                                                  _lib.ptr(cells, C.c_int32), cap, _lib.ptr(status, C.c_int32),
+                                                  _lib.ptr(cost, C.c_double), C.byref(secs))
+                if rc == _lib.E_ARG and offsets[n] > cap:
+                    cap = int(offsets[n])
+                    continue
+                self._chk(rc)
+                break
+            if auto and mpl < limit and (status == _lib.Q_PATH_TOO_LONG).any():
+                mpl = min(limit, mpl * 8)  # rare: a path with more jump points than the default slot
+                continue
+            break
+        self.last_seconds = secs.value
+        return offsets, cells[:offsets[n]], cost, status
+
+    def plan(self, start, goal, hchoice=2):
+        """plan(start, goal) -> waypoint list [(x, y), ...] (jump points, start and
+        goal inclusive); [] when there is no path."""
+        offsets, cells, cost, status = self.plan_batch([start], [goal], hchoice)
+        self.last_cost = float(cost[0])
+        if status[0] == _lib.Q_BAD_START:
+            raise IndexError("start %r is outside the %dx%d grid" % (tuple(start), self.shape[0], self.shape[1]))
+        if status[0] < 0:
+            raise FxjpsError(int(status[0]), "query failed")
+        return [(int(x), int(y)) for x, y in cells[offsets[0]:offsets[1]]]
+
+    def timing(self):
+        t = _lib.Timing()
+        self._chk(self._L.fxjps_last_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}
+
+    # -- test hooks
+    def selftest_sqrt(self, n0, n1):
+        out = np.empty(n1 - n0, dtype=np.float64)
+        self._chk(self._L.fxjps_selftest_sqrt(self._h, n0, n1, _lib.ptr(out, C.c_double)))
+        return out
+
+    def debug_nbmask(self):
+        W, H = self.shape
+        buf = np.empty((W + 2, H + 2), dtype=np.uint8)
+        self._chk(self._L.fxjps_debug_read_nbmask(self._h, _lib.ptr(buf, C.c_uint8)))
+        return buf
+
+
+_default = None
+
+
+def default_planner():
+    """Process-wide planner on device 0 (what the jps1 shim uses)."""
+    global _default
+    if _default is None:
+        _default = Planner([0])
+    return _default
+
+
+def plan(grid, start, goal, hchoice=2):
+    """north_star call surface: plan(grid, start, goal) -> waypoint list."""
+    p = default_planner()
+    p.set_grid(grid)
+    return p.plan(start, goal, hchoice)
+
+
+def plan_batch(grid, starts, goals, hchoice=2, max_path_len=None):
+    p = default_planner()
+    p.set_grid(grid)
+    return p.plan_batch(starts, goals, hchoice, max_path_len)

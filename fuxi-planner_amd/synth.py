@@ -1,0 +1,66 @@
+"""Deterministic synthetic inputs for the benchmark configurations.
+
+Counter-based splitmix64, so that Python (numpy), C (oracle/jps_oracle.c) and any
+other implementation produce bit-identical grids and query sets:
+
+    key      = splitmix64(seed)
+    occ(x,y) = (splitmix64(key ^ (x*H + y)) >> 32) < floor(p * 2^32)
+
+    qkey = splitmix64(qseed ^ 0x51554552494553)
+    query i, endpoint k (0 start, 1 goal), attempt t:
+        r = splitmix64(qkey ^ (i << 20 | k << 16 | t));  x = (r >> 32) % W;  y = (r & 0xffffffff) % H
+    first attempt that lands on a free cell (and, for the goal, differs from the start) wins.
+"""
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    """Vectorised splitmix64 finaliser on uint64 arrays (wraps mod 2^64)."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & _M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M
+        return z ^ (z >> np.uint64(31))
+
+
+def synth_grid(W, H, seed, p=0.20):
+    """uint8 [W][H] occupancy, 1 = obstacle."""
+    key = splitmix64(np.array([seed], dtype=np.uint64))[0]
+    p32 = np.uint64(int(np.floor(p * 4294967296.0)))
+    idx = np.arange(W * H, dtype=np.uint64)
+    h = splitmix64(key ^ idx)
+    return ((h >> np.uint64(32)) < p32).astype(np.uint8).reshape(W, H)
+
+
+def synth_queries(occ, qseed, n, first=0):
+    """-> (starts int32[n,2], goals int32[n,2]) on free cells, start != goal."""
+    occ = np.asarray(occ)
+    W, H = occ.shape
+    qkey = splitmix64(np.array([np.uint64(qseed) ^ np.uint64(0x51554552494553)], dtype=np.uint64))[0]
+    i = (np.arange(n, dtype=np.uint64) + np.uint64(first)) << np.uint64(20)
+    out = []
+    start = None
+    for k in (0, 1):
+        xy = np.zeros((n, 2), dtype=np.int64)
+        todo = np.ones(n, dtype=bool)
+        t = 0
+        while todo.any():
+            if t >= 65536:
+                raise RuntimeError("no free cell found")
+            r = splitmix64(qkey ^ (i[todo] | np.uint64(k << 16) | np.uint64(t)))
+            x = ((r >> np.uint64(32)) % np.uint64(W)).astype(np.int64)
+            y = ((r & np.uint64(0xFFFFFFFF)) % np.uint64(H)).astype(np.int64)
+            ok = occ[x, y] == 0
+            if k == 1:
+                ok &= ~((x == start[todo, 0]) & (y == start[todo, 1]))
+            ids = np.flatnonzero(todo)
+            xy[ids[ok], 0] = x[ok]
+            xy[ids[ok], 1] = y[ok]
+            todo[ids[ok]] = False
+            t += 1
+        if k == 0:
+            start = xy
+        out.append(xy.astype(np.int32))
+    return out[0], out[1]

@@ -1,0 +1,133 @@
+/*
+ * fxjps.h -- C ABI of libfxjps.so: batched Jump-Point-Search A* on MI355X (gfx950).
+ *
+ * Drop-in boundary for the one hot path of fuxi-planner, the grid search
+ *     jps1.method(matrix, start, goal, hchoice)            scripts/jps1.py:183-230
+ * called once per planner tick from
+ *     scripts/global_planner_st.py:285 and scripts/global_planner_ccst.py:477.
+ * The Python shim (fuxi-planner_amd/jps1.py, ctypes) is the only thing the ROS
+ * node sees; everything below is what that shim binds.  Plain pointers and
+ * sizes only -- no C++ types, no torch types, no exceptions cross this ABI.
+ *
+ * Conventions (same as the reference):
+ *   - grid is W x H, indexed matrix[x][y], row-major with y contiguous
+ *     (occ[x*H + y]); a cell is an obstacle iff its byte is non-zero (the shim
+ *     converts with `matrix == 1`, jps1.py:20-29);
+ *   - cells are (x, y) int32 pairs; a path is the list of JUMP POINTS from
+ *     start to goal inclusive, exactly the list jps1.method returns
+ *     (jps1.py:200-205), and its cost is the float64 it prints (jps1.py:207);
+ *   - hchoice 1 = octile x10/x14, 2 = Euclidean (jps1.py:3-12, 232-246).
+ *
+ * Ownership: the caller owns every host buffer it passes; the library never
+ * keeps a pointer past the call.  The handle owns all device memory, streams
+ * and communicators.  Threading: a handle is not thread-safe; distinct handles
+ * are independent.  All calls block until their results are in host memory.
+ *
+ * Errors: every int-returning function returns FXJPS_OK (0) or a negative
+ * code; fxjps_last_error() then describes it.  Per-query conditions never
+ * abort a batch: they are reported in out_len[q].
+ */
+#ifndef FXJPS_H
+#define FXJPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fxjps fxjps_t;
+
+/* library-level return codes */
+#define FXJPS_OK 0
+#define FXJPS_E_ARG (-1)     /* bad argument (NULL, sizes, hchoice not in {1,2}: jps1.py:188 TypeError) */
+#define FXJPS_E_NODEV (-2)   /* no usable HIP device: the planner has no CPU fallback */
+#define FXJPS_E_HIP (-3)     /* a HIP runtime call failed */
+#define FXJPS_E_NOGRID (-4)  /* plan before set_grid */
+#define FXJPS_E_NOMEM (-5)
+#define FXJPS_E_COMM (-6)    /* RCCL failure (multi-device handle) */
+
+/* per-query codes in out_len[q] */
+#define FXJPS_Q_NOPATH 0           /* jps1.method returned (0, t): jps1.py:230 */
+#define FXJPS_Q_PATH_TOO_LONG (-1) /* more than max_path_len jump points; cost is still valid */
+#define FXJPS_Q_BAD_START (-2)     /* start outside the grid: the reference raises IndexError */
+#define FXJPS_Q_CAPACITY (-3)      /* search state outgrew device scratch even after the large-scratch retry */
+
+/* backend ids for fxjps_create: only the HIP backend exists. */
+#define FXJPS_BACKEND_HIP 1
+
+int fxjps_version(void);
+
+/* Number of HIP devices visible, or a negative code. */
+int fxjps_device_count(void);
+
+/* Create a planner on the given devices (device_ids == NULL: devices 0..n_dev-1).
+ * n_dev > 1 shards every batch over the devices in contiguous slices and
+ * broadcasts the grid from device_ids[0] with RCCL.  backend must be
+ * FXJPS_BACKEND_HIP; there is no CPU backend. */
+int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out);
+
+void fxjps_destroy(fxjps_t* h);
+
+/* Last error text for this handle (h == NULL: last create error). */
+const char* fxjps_last_error(fxjps_t* h);
+
+/* Upload an occupancy grid (copies; replaces the previous one) and rebuild the
+ * derived device maps.  Replaces the `matrix` argument of jps1.method. */
+int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H);
+
+/* Same, but `d_occ` already lives in the memory of the handle's first device
+ * (e.g. the receive buffer of a collective the host framework ran). */
+int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H);
+
+/* Streaming replan: set n cells (xy pairs) to val[i] (0 free / non-zero
+ * obstacle) on the resident grid and rebuild the derived maps. */
+int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
+
+/* Plan nq independent (start, goal) queries against the resident grid.
+ *   starts_xy, goals_xy : nq (x, y) pairs
+ *   out_cells_xy        : nq * max_path_len (x, y) pairs; query q's jump points
+ *                         start at out_cells_xy + q*max_path_len*2 (may be NULL)
+ *   out_len             : nq; >0 number of jump points, else a FXJPS_Q_* code
+ *   out_cost            : nq float64 path costs (gscore[goal], jps1.py:207); 0 if no path
+ *   out_seconds_total   : wall seconds spent inside the call (may be NULL)
+ */
+int fxjps_plan_batch(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq,
+                     int32_t hchoice, int32_t max_path_len, int32_t* out_cells_xy,
+                     int32_t* out_len, double* out_cost, double* out_seconds_total);
+
+/* Same search, compact result: out_offsets has nq+1 entries, query q's jump
+ * points are out_cells_xy[2*out_offsets[q] .. 2*out_offsets[q+1]).  Queries
+ * without a path contribute zero cells.  cells_capacity is the number of
+ * (x, y) pairs out_cells_xy can hold; if the batch needs more the call
+ * returns FXJPS_E_ARG after filling out_len/out_cost/out_offsets so the
+ * caller can size the buffer (out_offsets[nq]) and call again. */
+int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy,
+                         int64_t nq, int32_t hchoice, int32_t max_path_len,
+                         int64_t* out_offsets, int32_t* out_cells_xy, int64_t cells_capacity,
+                         int32_t* out_len, double* out_cost, double* out_seconds_total);
+
+/* Measurement hooks (bench.py, tests). */
+typedef struct fxjps_timing {
+    double search_kernel_ms; /* HIP-event time of the search kernel launches of the last batch */
+    double total_ms;         /* wall time of the last batch call */
+    int64_t search_launches; /* kernel launches that made up search_kernel_ms */
+    int64_t retried;         /* queries re-run with large scratch */
+    int64_t pops;            /* open-list pops executed by the last batch (all devices) */
+    int64_t pushes;
+} fxjps_timing_t;
+int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
+
+/* Device self-test: sqrt((double)n) for n in [n0, n1) written to out (host).
+ * Used by the tests to prove the device square root is the correctly rounded
+ * one math.sqrt gives (jps1.py:12,246). */
+int fxjps_selftest_sqrt(fxjps_t* h, uint32_t n0, uint32_t n1, double* out);
+
+/* Copy the derived device maps back for inspection (tests): the padded
+ * (W+2)x(H+2) neighbour-mask bytes.  buf must hold (W+2)*(H+2) bytes. */
+int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
