@@ -106,6 +106,7 @@ struct DevCtx {
     int W = 0, H = 0, PW = 0, PH = 0, NS = 0, RW = 0, CW = 0;
     DBuf<uint8_t> occ, nb8;
     DBuf<uint64_t> occR, stopYp, stopYm, occC, stopXp, stopXm;
+    DBuf<int> comp;
     // search scratch (two pools: the regular one and the large retry one)
     DBuf<TEnt> tables[2];
     DBuf<FarEnt> far[2];
@@ -114,7 +115,7 @@ struct DevCtx {
     // batch buffers
     DBuf<int32_t> d_starts, d_goals, d_len, d_cells;
     DBuf<double> d_cost;
-    DBuf<uint32_t> d_path, d_order;
+    DBuf<uint32_t> d_path, d_order, d_redo;
     DBuf<long long> d_offsets;
     DBuf<unsigned int> d_next;
     DBuf<unsigned long long> d_counters;
@@ -124,6 +125,7 @@ struct DevCtx {
     HBuf<double> h_cost;
     HBuf<long long> h_offsets;
     HBuf<unsigned long long> h_counters;
+    std::vector<uint32_t> h_order;
     // shard of the current batch
     int64_t q0 = 0, nq = 0;
     double kernel_ms = 0;
@@ -138,6 +140,7 @@ struct fxjps {
     std::string err;
     bool have_grid = false;
     fxjps_timing_t timing{};
+    int64_t last_nq = 0;
     // RCCL (only for n_dev > 1), resolved with dlopen so that a single-GPU
     // deployment does not need librccl at load time
     void* rccl = nullptr;
@@ -176,7 +179,7 @@ GridDev grid_of(const DevCtx& d) {
     G.occC = d.occC.p;
     G.stopXp = d.stopXp.p;
     G.stopXm = d.stopXm.p;
-    G.comp = nullptr;
+    G.comp = d.comp.p;
     G.W = d.W;
     G.H = d.H;
     G.PW = d.PW;
@@ -196,6 +199,13 @@ int derive_maps(fxjps* h, DevCtx& d) {
     hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, d.W,
                        d.H, d.PW, d.PH, d.NS, d.CW, d.nb8.p, d.occC.p, d.stopXp.p, d.stopXm.p);
     HIPCHK(h, hipGetLastError());
+    // component labels for the unreachable-goal early-out
+    const long long n = (long long)d.W * d.H;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(fx::k_ccl_init, dim3(nb), dim3(256), 0, d.stream, d.occ.p, n, d.comp.p);
+    hipLaunchKernelGGL(fx::k_ccl_merge, dim3(nb), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.comp.p);
+    hipLaunchKernelGGL(fx::k_ccl_flatten, dim3(nb), dim3(256), 0, d.stream, n, d.comp.p);
+    HIPCHK(h, hipGetLastError());
     return FXJPS_OK;
 }
 
@@ -209,6 +219,7 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     d.RW = (d.PH + 63) / 64;
     d.CW = (d.PW + 63) / 64;
     HIPCHK(h, d.occ.ensure((size_t)W * H));
+    HIPCHK(h, d.comp.ensure((size_t)W * H));
     HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
     const size_t nr = (size_t)d.PW * d.RW, nc = (size_t)d.PH * d.CW;
     HIPCHK(h, d.occR.ensure(nr));
@@ -232,11 +243,13 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     const uint64_t cells = (uint64_t)d.W * d.H;
     ScratchCfg c;
     if (pool == 0) {
-        // typical query touches ~4 % of the cells (37 k pushes on 1 Mi cells)
-        uint32_t l2e = ceil_log2(std::max<uint64_t>(cells / 16, 1));  // entries
-        l2e = std::min(std::max(l2e, 12u), 21u);
+        // measured on the config-2 workload (1024^2, 20 %): a reachable query inserts 34 k nodes
+        // on average, 117 k at p99, 139 k at most, and keeps at most 2.4 k entries open; a table
+        // of cells/4 entries (3/4 usable) covers all of them, the retry pool covers the rest
+        uint32_t l2e = ceil_log2(std::max<uint64_t>(cells / 4, 1));  // entries
+        l2e = std::min(std::max(l2e, 12u), 23u);
         c.log2_buckets = l2e - 3;
-        c.far_cap = std::max<uint32_t>(1024u, (8u << c.log2_buckets) / 4);
+        c.far_cap = std::max<uint32_t>(2048u, (8u << c.log2_buckets) / 16);
         c.nwaves = want_waves;
     } else {
         const uint32_t l2e = std::max(ceil_log2(cells * 2 + 64), 12u);
@@ -328,20 +341,38 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     HIPCHK(h, d.d_path.ensure((size_t)nq * max_len));
     HIPCHK(h, d.d_offsets.ensure((size_t)nq + 1));
     HIPCHK(h, d.d_next.ensure(4));
-    HIPCHK(h, d.d_counters.ensure(4));
+    HIPCHK(h, d.d_counters.ensure(32));
     HIPCHK(h, d.h_len.ensure((size_t)nq));
     HIPCHK(h, d.h_cost.ensure((size_t)nq));
     HIPCHK(h, d.h_offsets.ensure((size_t)nq + 1));
-    HIPCHK(h, d.h_counters.ensure(4));
+    HIPCHK(h, d.h_counters.ensure(32));
     HIPCHK(h, hipMemcpyAsync(d.d_starts.p, starts + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.d_goals.p, goals + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 4 * sizeof(unsigned long long), d.stream));
+    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 32 * sizeof(unsigned long long), d.stream));
     const uint32_t full = (uint32_t)d.n_cu * 32u;
+    // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
+    // on the config-2 workload), so far-apart queries are handed out first and the short ones fill
+    // the tail.  Counting sort on the Chebyshev distance, descending.
+    {
+        const int32_t* S = starts + 2 * d.q0;
+        const int32_t* G = goals + 2 * d.q0;
+        std::vector<uint32_t> head(8194, 0);
+        d.h_order.resize((size_t)nq);
+        auto key = [&](int64_t i) -> uint32_t {
+            const int64_t dx = std::llabs((int64_t)S[2 * i] - G[2 * i]), dy = std::llabs((int64_t)S[2 * i + 1] - G[2 * i + 1]);
+            return (uint32_t)std::min<int64_t>(std::max(dx, dy), 8191);
+        };
+        for (int64_t i = 0; i < nq; i++) head[8191 - key(i) + 1]++;
+        for (int k = 1; k < 8194; k++) head[k] += head[k - 1];
+        for (int64_t i = 0; i < nq; i++) d.h_order[head[8191 - key(i)]++] = (uint32_t)i;
+        HIPCHK(h, d.d_order.ensure((size_t)nq));
+        HIPCHK(h, hipMemcpyAsync(d.d_order.p, d.h_order.data(), (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+    }
     DBG("run_shard nq=%lld: inputs queued", (long long)nq);
     int rc = ensure_pool(h, d, 0, (uint32_t)std::min<int64_t>(full, (nq + 3) & ~3ll));
     if (rc) return rc;
     DBG("pool ready");
-    rc = launch_search(h, d, 0, nullptr, (uint32_t)nq, hchoice, max_len);
+    rc = launch_search(h, d, 0, d.d_order.p, (uint32_t)nq, hchoice, max_len);
     if (rc) return rc;
     return FXJPS_OK;
 }
@@ -366,9 +397,10 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
         d.retried = (int64_t)redo.size();
         int rc = ensure_pool(h, d, 1, (uint32_t)std::min<size_t>(256, (redo.size() + 3) & ~(size_t)3));
         if (rc) return rc;
-        HIPCHK(h, d.d_order.ensure(redo.size()));
-        HIPCHK(h, hipMemcpyAsync(d.d_order.p, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
-        rc = launch_search(h, d, 1, d.d_order.p, (uint32_t)redo.size(), hchoice, max_len);
+        HIPCHK(h, d.d_redo.ensure(redo.size()));
+        HIPCHK(h, hipMemcpyAsync(d.d_redo.p, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipStreamSynchronize(d.stream));  // `redo` is pageable host memory
+        rc = launch_search(h, d, 1, d.d_redo.p, (uint32_t)redo.size(), hchoice, max_len);
         if (rc) return rc;
         HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
         HIPCHK(h, hipStreamSynchronize(d.stream));
@@ -380,7 +412,7 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(d.h_offsets.p, d.d_offsets.p, ((size_t)nq + 1) * sizeof(long long), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.h_cost.p, d.d_cost.p, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, d.stream));
-    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(h, hipStreamSynchronize(d.stream));
     const long long total = d.h_offsets.p[nq];
     DBG("scan done, %lld cells", total);
@@ -550,6 +582,7 @@ void fxjps_destroy(fxjps_t* h) {
         (void)hipSetDevice(d.dev);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         d.occ.release();
+        d.comp.release();
         d.nb8.release();
         d.occR.release();
         d.stopYp.release();
@@ -568,6 +601,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_cost.release();
         d.d_path.release();
         d.d_order.release();
+        d.d_redo.release();
         d.d_offsets.release();
         d.d_next.release();
         d.d_counters.release();
@@ -664,16 +698,34 @@ int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* go
         memcpy(out_cost + d.q0, d.h_cost.p, (size_t)d.nq * sizeof(double));
         for (int64_t i = 0; i < d.nq; i++) out_offsets[d.q0 + i] = base + d.h_offsets.p[i];
         const int64_t total = d.h_offsets.p[d.nq];
-        if (base + total > cells_capacity || (total > 0 && !out_cells_xy))
+        if (!out_cells_xy) {
+            // sizing call: the cells stay in the handle for fxjps_last_cells()
+        } else if (base + total > cells_capacity) {
             fits = false;
-        else if (total > 0)
+        } else if (total > 0) {
             memcpy(out_cells_xy + 2 * base, d.h_cells.p, (size_t)total * 2 * sizeof(int32_t));
+        }
         base += total;
     }
     if (out_offsets) out_offsets[nq] = base;
+    h->last_nq = nq;
     h->timing.total_ms = (now_s() - t0) * 1e3;
     if (out_seconds_total) *out_seconds_total = now_s() - t0;
     if (!fits) return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, batch needs %lld", (long long)cells_capacity, (long long)base);
+    return FXJPS_OK;
+}
+
+int fxjps_last_cells(fxjps_t* h, int32_t* out_cells_xy, int64_t cells_capacity) {
+    if (!h || !out_cells_xy) return FXJPS_E_ARG;
+    int64_t base = 0;
+    for (auto& d : h->devs) {
+        if (d.nq == 0 || !d.h_offsets.p) continue;
+        const int64_t total = d.h_offsets.p[d.nq];
+        if (base + total > cells_capacity)
+            return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, the last batch has more", (long long)cells_capacity);
+        if (total > 0) memcpy(out_cells_xy + 2 * base, d.h_cells.p, (size_t)total * 2 * sizeof(int32_t));
+        base += total;
+    }
     return FXJPS_OK;
 }
 
@@ -740,6 +792,16 @@ unsigned int* fxjps_debug_trace_ptr(fxjps_t* h) {
     return d.trace;
 }
 #endif
+
+// raw device counters of the last batch on device 0: [0] pops [1] pushes [2] refills [3] slow pops,
+// [8..17] per-phase cycles in FXJPS_PROF builds (tools only; not declared in fxjps.h)
+int fxjps_debug_counters(fxjps_t* h, unsigned long long* out32) {
+    if (!h || !out32) return FXJPS_E_ARG;
+    DevCtx& d = h->devs[0];
+    if (!d.h_counters.p) return FXJPS_E_ARG;
+    memcpy(out32, d.h_counters.p, 32 * sizeof(unsigned long long));
+    return FXJPS_OK;
+}
 
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf) {
     if (!h || !buf) return FXJPS_E_ARG;

@@ -115,25 +115,21 @@ class Planner(object):
             offsets = np.zeros(n + 1, dtype=np.int64)
             status = np.zeros(n, dtype=np.int32)
             cost = np.zeros(n, dtype=np.float64)
-            cap = max(1024, n * 64)
             secs = C.c_double(0.0)
-            while True:
-                cells = np.empty((cap, 2), dtype=np.int32)
-                rc = self._L.fxjps_plan_batch_csr(self._h, _lib.ptr(starts, C.c_int32), _lib.ptr(goals, C.c_int32), n,
-                                                  int(hchoice), mpl, _lib.ptr(offsets, C.c_int64),
-                                                  _lib.ptr(cells, C.c_int32), cap, _lib.ptr(status, C.c_int32),
-                                                  _lib.ptr(cost, C.c_double), C.byref(secs))
-                if rc == _lib.E_ARG and offsets[n] > cap:
-                    cap = int(offsets[n])
-                    continue
-                self._chk(rc)
-                break
+            # sizing call (cells stay in the handle), then one copy into an exactly sized array
+            self._chk(self._L.fxjps_plan_batch_csr(self._h, _lib.ptr(starts, C.c_int32), _lib.ptr(goals, C.c_int32), n,
+                                                   int(hchoice), mpl, _lib.ptr(offsets, C.c_int64), None, 0,
+                                                   _lib.ptr(status, C.c_int32), _lib.ptr(cost, C.c_double),
+                                                   C.byref(secs)))
+            cells = np.empty((int(offsets[n]), 2), dtype=np.int32)
+            if offsets[n] > 0:
+                self._chk(self._L.fxjps_last_cells(self._h, _lib.ptr(cells, C.c_int32), int(offsets[n])))
             if auto and mpl < limit and (status == _lib.Q_PATH_TOO_LONG).any():
                 mpl = min(limit, mpl * 8)  # rare: a path with more jump points than the default slot
                 continue
             break
         self.last_seconds = secs.value
-        return offsets, cells[:offsets[n]], cost, status
+        return offsets, cells, cost, status
 
     def plan(self, start, goal, hchoice=2):
         """plan(start, goal) -> waypoint list [(x, y), ...] (jump points, start and

@@ -99,13 +99,18 @@ int fxjps_plan_batch(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_
 /* Same search, compact result: out_offsets has nq+1 entries, query q's jump
  * points are out_cells_xy[2*out_offsets[q] .. 2*out_offsets[q+1]).  Queries
  * without a path contribute zero cells.  cells_capacity is the number of
- * (x, y) pairs out_cells_xy can hold; if the batch needs more the call
- * returns FXJPS_E_ARG after filling out_len/out_cost/out_offsets so the
- * caller can size the buffer (out_offsets[nq]) and call again. */
+ * (x, y) pairs out_cells_xy can hold.  Pass out_cells_xy == NULL to get
+ * out_len/out_cost/out_offsets only; the cells of the batch stay in the
+ * handle and fxjps_last_cells() copies them once the caller has sized a
+ * buffer from out_offsets[nq].  A non-NULL buffer that is too small makes
+ * the call return FXJPS_E_ARG (everything but the cells is filled in). */
 int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy,
                          int64_t nq, int32_t hchoice, int32_t max_path_len,
                          int64_t* out_offsets, int32_t* out_cells_xy, int64_t cells_capacity,
                          int32_t* out_len, double* out_cost, double* out_seconds_total);
+
+/* Copy the jump points of the most recent batch (CSR order) into out_cells_xy. */
+int fxjps_last_cells(fxjps_t* h, int32_t* out_cells_xy, int64_t cells_capacity);
 
 /* Measurement hooks (bench.py, tests). */
 typedef struct fxjps_timing {

@@ -1,0 +1,139 @@
+"""CPU suite: the C-ABI library loads and exports what include/fxjps.h declares, the host code
+fails loudly without a GPU, and the multi-process shard/broadcast logic (gloo, world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from fuxi_planner_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.LIB_PATH
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    hdr = open(os.path.join(ROOT, "include", "fxjps.h")).read()
+    declared = set(re.findall(r"\b(fxjps_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 13
+    L = C.CDLL(libpath)
+    for name in sorted(declared):
+        assert hasattr(L, name), "libfxjps.so does not export %s" % name
+    from fuxi_planner_amd import _lib
+    assert declared == set(_lib.SYMBOLS)
+    assert L.fxjps_version() >= 100
+
+
+def _have_gpu(libpath):
+    return C.CDLL(libpath).fxjps_device_count() > 0
+
+
+def test_no_cpu_fallback(libpath):
+    """Without a GPU the planner must refuse to work rather than silently run on the host."""
+    if _have_gpu(libpath):
+        pytest.skip("a GPU is visible")
+    import fuxi_planner_amd as fx
+    with pytest.raises(fx.FxjpsError) as e:
+        fx.Planner()
+    assert e.value.code == -2
+    with pytest.raises(fx.FxjpsError):
+        fx.jps1.method(np.zeros((5, 5)), (0, 0), (4, 4), 2)
+    L = C.CDLL(libpath)
+    h = C.c_void_p()
+    assert L.fxjps_create(1, None, 1, C.byref(h)) == -2 and not h.value
+    assert L.fxjps_create(0, None, 1, C.byref(h)) == -1  # no CPU backend exists
+    L.fxjps_last_error.restype = C.c_char_p
+    assert b"CPU" in L.fxjps_last_error(None)
+
+
+def test_missing_library_is_loud(tmp_path):
+    code = ("import os,sys; sys.path.insert(0, %r); os.environ['FXJPS_LIB']=%r\n"
+            "import fuxi_planner_amd as fx\n"
+            "try:\n    fx.Planner()\nexcept fx.FxjpsError as e:\n    print('LOUD', e.code)\n") % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "LOUD -2" in out.stdout, out.stdout + out.stderr
+
+
+def test_as_occ_semantics():
+    """Only cells equal to 1 are obstacles (jps1.py:20-29): 100, -1, 0.5 are free."""
+    from fuxi_planner_amd import as_occ
+    m = np.array([[0, 1, 100], [-1, 0.5, 1.0]])
+    assert as_occ(m).tolist() == [[0, 1, 0], [0, 0, 1]]
+    assert as_occ(m).dtype == np.uint8 and as_occ(m).flags.c_contiguous
+
+
+def test_shard_bounds_partition():
+    from fuxi_planner_amd.distributed import shard_bounds
+    for nq in (0, 1, 7, 10000, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(nq, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == nq
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            assert max(hi - lo for lo, hi in edges) - min(hi - lo for lo, hi in edges) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from fuxi_planner_amd.distributed import ShardedPlanner
+from oracle import oracle
+
+class CheckerEngine(object):
+    """Test double for the per-rank Planner (same call surface), backed by the CPU oracle."""
+    def set_grid_occ(self, occ):
+        self.occ = np.array(occ, dtype=np.uint8)
+    def plan_batch(self, starts, goals, hchoice=2, max_path_len=None):
+        cells, ln, cost, _ = oracle.plan_batch(self.occ, starts, goals, hchoice, max_len=max_path_len or 512)
+        off = np.zeros(len(ln) + 1, dtype=np.int64); off[1:] = np.cumsum(np.maximum(ln, 0))
+        flat = np.concatenate([cells[q, :max(ln[q], 0)] for q in range(len(ln))] or [np.zeros((0, 2), np.int32)])
+        return off, flat, cost, ln
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+sp = ShardedPlanner(CheckerEngine(), device="cpu")
+occ = oracle.synth_grid(96, 64, 11, 0.25) if rank == 0 else None
+W, H = sp.set_grid(occ)
+assert (W, H) == (96, 64)
+full = oracle.synth_grid(96, 64, 11, 0.25)
+assert np.array_equal(sp.engine.occ, full)            # the broadcast delivered the grid to every rank
+s, g = oracle.synth_queries(full, 5, 101)
+res = sp.plan(s, g, 2, 256)
+if rank == 0:
+    off, cells, cost, status = res
+    c1, l1, k1, _ = oracle.plan_batch(full, s, g, 2, max_len=256)
+    assert np.array_equal(status, l1) and np.array_equal(cost, k1)
+    for q in range(101):
+        assert np.array_equal(cells[off[q]:off[q + 1]], c1[q, :max(l1[q], 0)])
+    print("MERGED-OK", int(off[-1]))
+else:
+    assert res is None
+lo, hi = sp.plan_local(s, g, 2, 256)[:2]
+print("RANK", rank, lo, hi)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_shard_and_merge(tmp_path, oracle):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "MERGED-OK" in outs[0]
+    assert "RANK 0 0 50" in outs[0] and "RANK 1 50 101" in outs[1]

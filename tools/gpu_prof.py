@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the search kernel (diagnostic build libfxjps_prof.so)."""
+import ctypes as C, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if "--noprof" not in sys.argv:
+    os.environ["FXJPS_LIB"] = os.path.join(ROOT, "fuxi-planner_amd", "libfxjps_prof.so")
+import fuxi_planner_amd as fx
+from fuxi_planner_amd import synth, _lib
+W = int(os.environ.get("FX_W", "1024"))
+nqs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [128]
+p = fx.Planner([0])
+L = _lib.load()
+L.fxjps_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+occ = synth.synth_grid(W, W, 1 if W == 1024 else 2, 0.20)
+p.set_grid_occ(occ)
+names = ["pop", "entload", "nb8+dirs", "straight", "diag", "bcast", "probe", "write+push", "-", "looptop"]
+for nq in nqs:
+    s, g = synth.synth_queries(occ, 1 if W == 1024 else 2, nq)
+    for rep in range(2):
+        t = time.time(); off, cells, cost, st = p.plan_batch(s, g, 2, 1024 if W == 1024 else 4096); dt = time.time() - t
+    tm = p.timing()
+    c = (C.c_uint64 * 32)(); L.fxjps_debug_counters(p._h, c); c = list(c)
+    print("nq=%d wall %.3fs kernel %.1f ms -> %.0f plans/s | pops %d pushes %d refills %d slow %d retried %d nopath %d" % (
+        nq, dt, tm["search_kernel_ms"], nq / dt, c[0], c[1], c[2], c[3], tm["retried"], int((st == 0).sum())), flush=True)
+    tot = sum(c[8:18])
+    if tot:
+        print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10) if k != 8), flush=True)
