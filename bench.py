@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the host cores")
+    ap.add_argument("--cpu-sample", type=int, default=10000, help="queries timed on the host cores")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

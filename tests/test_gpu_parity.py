@@ -170,9 +170,11 @@ def test_structured_maps_vs_oracle(planner, oracle):
     n = 400
     s = free[rng.integers(0, len(free), n)].astype(np.int32)
     g = free[rng.integers(0, len(free), n)].astype(np.int32)
+    g[:20] = [104, 104]  # into the sealed pocket: exhaustive (0, t) in the reference
+    s[20:30] = [104, 105]  # out of it
     planner.set_grid_occ(occ)
     off, cells, cost, st = gpu_vs_oracle(planner, oracle, occ, s, g, 2)
-    assert (st == 0).any() and (st > 0).any()
+    assert (st[:30] == 0).all() and (st > 0).any()
 
 
 # ------------------------------------------------------------------ edge cases of the reference
