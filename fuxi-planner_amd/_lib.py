@@ -15,7 +15,7 @@ BACKEND_HIP = 1
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_update_cells", "fxjps_plan_batch",
-           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_debug_read_nbmask")
+           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_debug_read_nbmask")
 
 
 class Timing(C.Structure):
@@ -71,6 +71,8 @@ def load():
     L.fxjps_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.fxjps_selftest_sqrt.restype = C.c_int
     L.fxjps_selftest_sqrt.argtypes = [vp, C.c_uint32, C.c_uint32, p_f64]
+    L.fxjps_selftest_wavemin.restype = C.c_int
+    L.fxjps_selftest_wavemin.argtypes = [vp, C.c_int32, C.c_uint64, p_i64]
     L.fxjps_debug_read_nbmask.restype = C.c_int
     L.fxjps_debug_read_nbmask.argtypes = [vp, p_u8]
     _lib = L

@@ -107,6 +107,7 @@ struct DevCtx {
     DBuf<uint8_t> occ, nb8;
     DBuf<uint64_t> occR, stopYp, stopYm, occC, stopXp, stopXm;
     DBuf<int> comp;
+    DBuf<uint16_t> ci;
     // search scratch (two pools: the regular one and the large retry one)
     DBuf<TEnt> tables[2];
     DBuf<FarEnt> far[2];
@@ -173,6 +174,7 @@ int fail(fxjps* h, int code, const char* fmt, ...) {
 GridDev grid_of(const DevCtx& d) {
     GridDev G;
     G.nb8 = d.nb8.p;
+    G.ci = d.ci.p;
     G.occR = d.occR.p;
     G.stopYp = d.stopYp.p;
     G.stopYm = d.stopYm.p;
@@ -198,6 +200,11 @@ int derive_maps(fxjps* h, DevCtx& d) {
                        d.H, d.PW, d.PH, d.NS, d.RW, d.nb8.p, d.occR.p, d.stopYp.p, d.stopYm.p);
     hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, d.W,
                        d.H, d.PW, d.PH, d.NS, d.CW, d.nb8.p, d.occC.p, d.stopXp.p, d.stopXm.p);
+    {
+        const long long ncell = (long long)d.PW * d.PH;
+        hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream,
+                           grid_of(d), d.ci.p);
+    }
     HIPCHK(h, hipGetLastError());
     // component labels for the unreachable-goal early-out
     const long long n = (long long)d.W * d.H;
@@ -221,6 +228,7 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     HIPCHK(h, d.occ.ensure((size_t)W * H));
     HIPCHK(h, d.comp.ensure((size_t)W * H));
     HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
+    HIPCHK(h, d.ci.ensure((size_t)d.PW * d.NS));
     const size_t nr = (size_t)d.PW * d.RW, nc = (size_t)d.PH * d.CW;
     HIPCHK(h, d.occR.ensure(nr));
     HIPCHK(h, d.stopYp.ensure(nr));
@@ -584,6 +592,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.occ.release();
         d.comp.release();
         d.nb8.release();
+        d.ci.release();
         d.occR.release();
         d.stopYp.release();
         d.stopYm.release();
@@ -800,6 +809,46 @@ int fxjps_debug_counters(fxjps_t* h, unsigned long long* out32) {
     DevCtx& d = h->devs[0];
     if (!d.h_counters.p) return FXJPS_E_ARG;
     memcpy(out32, d.h_counters.p, 32 * sizeof(unsigned long long));
+    return FXJPS_OK;
+}
+
+int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* mismatches) {
+    if (!h || !mismatches || rounds < 1 || rounds > (1 << 16)) return FXJPS_E_ARG;
+    DevCtx& d = h->devs[0];
+    HIPCHK(h, hipSetDevice(d.dev));
+    std::vector<uint64_t> in((size_t)rounds * 64), out((size_t)rounds * 4);
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    for (size_t i = 0; i < in.size(); i++) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        // mix of wide-range values and many ties
+        in[i] = (i % 7 == 0) ? (x & 0xFF) : ((i % 5 == 0) ? (x | 0xFFFFFFFF00000000ull) : x);
+    }
+    uint64_t *din = nullptr, *dout = nullptr;
+    HIPCHK(h, hipMalloc((void**)&din, in.size() * 8));
+    HIPCHK(h, hipMalloc((void**)&dout, out.size() * 8));
+    hipError_t e = hipMemcpy(din, in.data(), in.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fx::k_selftest_wavemin, dim3(1), dim3(64), 0, d.stream, din, dout, rounds);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    if (e == hipSuccess) e = hipMemcpy(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(h, FXJPS_E_HIP, "selftest: %s", hipGetErrorString(e));
+    int64_t bad = 0;
+    for (int r = 0; r < rounds; r++) {
+        uint64_t m64 = ~0ull;
+        uint32_t m32 = ~0u;
+        for (int l = 0; l < 64; l++) {
+            m64 = std::min(m64, in[(size_t)r * 64 + l]);
+            m32 = std::min(m32, (uint32_t)(in[(size_t)r * 64 + l] >> 7));
+        }
+        if (out[(size_t)r * 4] != m64 || out[(size_t)r * 4 + 1] != m64 || out[(size_t)r * 4 + 2] != m32 || out[(size_t)r * 4 + 3] != m32) bad++;
+    }
+    *mismatches = bad;
     return FXJPS_OK;
 }
 

@@ -153,6 +153,11 @@ class Planner(object):
         self._chk(self._L.fxjps_selftest_sqrt(self._h, n0, n1, _lib.ptr(out, C.c_double)))
         return out
 
+    def selftest_wavemin(self, rounds=4096, seed=1):
+        bad = C.c_int64(-1)
+        self._chk(self._L.fxjps_selftest_wavemin(self._h, rounds, seed, C.byref(bad)))
+        return bad.value
+
     def debug_nbmask(self):
         W, H = self.shape
         buf = np.empty((W + 2, H + 2), dtype=np.uint8)

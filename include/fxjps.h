@@ -128,6 +128,10 @@ int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
  * one math.sqrt gives (jps1.py:12,246). */
 int fxjps_selftest_sqrt(fxjps_t* h, uint32_t n0, uint32_t n1, double* out);
 
+/* Device self-test of the wavefront-wide DPP minimum used by the open list against the
+ * shuffle form and a host reference, on `rounds` rows of 64 pseudo-random values. */
+int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* mismatches);
+
 /* Copy the derived device maps back for inspection (tests): the padded
  * (W+2)x(H+2) neighbour-mask bytes.  buf must hold (W+2)*(H+2) bytes. */
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);

@@ -55,6 +55,12 @@ def test_device_sqrt_is_correctly_rounded(planner):
     assert planner.selftest_sqrt(2, 3)[0] == math.sqrt(2)
 
 
+def test_wavefront_minimum(planner):
+    """The DPP reduction behind every open-list pop equals the shuffle form and a host minimum."""
+    assert planner.selftest_wavemin(4096, 1) == 0
+    assert planner.selftest_wavemin(1000, 99) == 0
+
+
 # ------------------------------------------------------------------ golden vectors from jps1.py
 def test_known_answers_through_the_jps1_shim(planner):
     """The drop-in module: same return tuple, same printed cost, `path1[0] is 0` for no path."""
