@@ -15,7 +15,7 @@ L = _lib.load()
 L.fxjps_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 occ = synth.synth_grid(W, W, 1 if W == 1024 else 2, 0.20)
 p.set_grid_occ(occ)
-names = ["pop", "entload", "nb8+dirs", "straight", "diag", "bcast", "probe", "write+push", "-", "looptop"]
+names = ["pop", "ec+close", "x:tail", "x:dirs+issue", "x:eval+diag", "x:more+bcast", "probe", "write+push", "pre-expand", "looptop"]
 for nq in nqs:
     s, g = synth.synth_queries(occ, 1 if W == 1024 else 2, nq)
     for rep in range(2):
@@ -26,4 +26,4 @@ for nq in nqs:
         nq, dt, tm["search_kernel_ms"], nq / dt, c[0], c[1], c[2], c[3], tm["retried"], int((st == 0).sum())), flush=True)
     tot = sum(c[8:18])
     if tot:
-        print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10) if k != 8), flush=True)
+        print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
