@@ -103,9 +103,9 @@ struct DevCtx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // grid
-    int W = 0, H = 0, PW = 0, PH = 0, NS = 0, RW = 0, CW = 0;
+    int W = 0, H = 0, PW = 0, PH = 0, NS = 0, LINES = 0, WORDS = 0;
     DBuf<uint8_t> occ, nb8;
-    DBuf<uint64_t> occR, stopYp, stopYm, occC, stopXp, stopXm;
+    DBuf<fx::BmWord> bm;
     DBuf<int> comp;
     DBuf<uint16_t> ci;
     // search scratch (two pools: the regular one and the large retry one)
@@ -131,7 +131,6 @@ struct DevCtx {
     int64_t q0 = 0, nq = 0;
     double kernel_ms = 0;
     int64_t launches = 0, retried = 0;
-    unsigned int* trace = nullptr;  // FXJPS_TRACE builds only
 };
 
 }  // namespace
@@ -171,35 +170,71 @@ int fail(fxjps* h, int code, const char* fmt, ...) {
                         #call, hipGetErrorString(e__), __FILE__, __LINE__);                      \
     } while (0)
 
+// nodeNeighbours (jps1.py:49-93) on a neighbour mask: which direction each of the 8 lane groups of
+// the search kernel follows.  pd = (dX+1)*4 + (dY+1) of direction(c, came_from[c]) (jps1.py:40-47),
+// 5 = no parent (the start node, `type(parent) != tuple`, :51).
+uint32_t dirlut_entry(uint32_t pd, uint32_t nbm) {
+    auto occ = [&](int dx, int dy) -> bool { return (nbm >> fx::nbit(dx, dy)) & 1u; };
+    auto blocked = [&](int dx, int dy) -> bool {  // blocked(c, dx, dy), jps1.py:14-31, border == occupied
+        if (dx != 0 && dy != 0) return (occ(dx, 0) && occ(0, dy)) || occ(dx, dy);
+        return occ(dx, dy);
+    };
+    uint32_t codes[8];
+    int n = 0;
+    auto add = [&](int dx, int dy) { codes[n++] = (uint32_t)((dx + 1) * 4 + (dy + 1)); };
+    const int pdx = (int)(pd >> 2) - 1, pdy = (int)(pd & 3u) - 1;
+    if (pd == fx::PD_NONE) {  // :51-56
+        static const int all8[8][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+        for (auto& d : all8)
+            if (!blocked(d[0], d[1])) add(d[0], d[1]);
+    } else if (pdx < -1 || pdx > 1 || pdy < -1 || pdy > 1) {
+        // not a direction code
+    } else if (pdx != 0 && pdy != 0) {  // :59-73
+        if (!blocked(0, pdy)) add(0, pdy);
+        if (!blocked(pdx, 0)) add(pdx, 0);
+        if ((!blocked(0, pdy) || !blocked(pdx, 0)) && !blocked(pdx, pdy)) add(pdx, pdy);
+        if (blocked(-pdx, 0) && !blocked(0, pdy)) add(-pdx, pdy);
+        if (blocked(0, -pdy) && !blocked(pdx, 0)) add(pdx, -pdy);
+    } else if (pdx == 0) {  // :76-83; the guard at :77 tests the node itself, which is free
+        if (!blocked(0, pdy)) add(0, pdy);
+        if (blocked(1, 0)) add(1, pdy);
+        if (blocked(-1, 0)) add(-1, pdy);
+    } else {  // :85-92
+        if (!blocked(pdx, 0)) {
+            add(pdx, 0);
+            if (blocked(0, 1)) add(pdx, 1);
+            if (blocked(0, -1)) add(pdx, -1);
+        }
+    }
+    uint32_t v = 0;
+    for (int g = 0; g < 8; g++) v |= (g < n ? codes[g] : fx::DIR_NONE) << (4 * g);
+    return v;
+}
+
 GridDev grid_of(const DevCtx& d) {
     GridDev G;
-    G.nb8 = d.nb8.p;
+    G.bm = d.bm.p;
     G.ci = d.ci.p;
-    G.occR = d.occR.p;
-    G.stopYp = d.stopYp.p;
-    G.stopYm = d.stopYm.p;
-    G.occC = d.occC.p;
-    G.stopXp = d.stopXp.p;
-    G.stopXm = d.stopXm.p;
+    G.nb8 = d.nb8.p;
     G.comp = d.comp.p;
     G.W = d.W;
     G.H = d.H;
     G.PW = d.PW;
     G.PH = d.PH;
     G.NS = d.NS;
-    G.RW = d.RW;
-    G.CW = d.CW;
+    G.LINES = d.LINES;
+    G.WORDS = d.WORDS;
     return G;
 }
 
 // (re)build nb8 + the six scan bitmaps from d.occ
 int derive_maps(fxjps* h, DevCtx& d) {
     HIPCHK(h, hipSetDevice(d.dev));
-    const long long nrw = (long long)d.PW * d.RW, ncw = (long long)d.PH * d.CW;
-    hipLaunchKernelGGL(fx::k_derive_rows, dim3((unsigned)((nrw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, d.W,
-                       d.H, d.PW, d.PH, d.NS, d.RW, d.nb8.p, d.occR.p, d.stopYp.p, d.stopYm.p);
-    hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, d.W,
-                       d.H, d.PW, d.PH, d.NS, d.CW, d.nb8.p, d.occC.p, d.stopXp.p, d.stopXm.p);
+    const long long nrw = (long long)d.PW * d.WORDS, ncw = (long long)d.PH * d.WORDS;
+    hipLaunchKernelGGL(fx::k_derive_rows, dim3((unsigned)((nrw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, grid_of(d),
+                       d.nb8.p, d.bm.p);
+    hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, grid_of(d),
+                       d.bm.p);
     {
         const long long ncell = (long long)d.PW * d.PH;
         hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream,
@@ -223,19 +258,13 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     d.PW = W + 2;
     d.PH = H + 2;
     d.NS = (d.PH + 63) & ~63;
-    d.RW = (d.PH + 63) / 64;
-    d.CW = (d.PW + 63) / 64;
+    d.LINES = std::max(d.PW, d.PH);
+    d.WORDS = (std::max(d.PW, d.PH) + 63) / 64;
     HIPCHK(h, d.occ.ensure((size_t)W * H));
     HIPCHK(h, d.comp.ensure((size_t)W * H));
     HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
     HIPCHK(h, d.ci.ensure((size_t)d.PW * d.NS));
-    const size_t nr = (size_t)d.PW * d.RW, nc = (size_t)d.PH * d.CW;
-    HIPCHK(h, d.occR.ensure(nr));
-    HIPCHK(h, d.stopYp.ensure(nr));
-    HIPCHK(h, d.stopYm.ensure(nr));
-    HIPCHK(h, d.occC.ensure(nc));
-    HIPCHK(h, d.stopXp.ensure(nc));
-    HIPCHK(h, d.stopXm.ensure(nc));
+    HIPCHK(h, d.bm.ensure((size_t)4 * d.LINES * d.WORDS));
     return FXJPS_OK;
 }
 
@@ -306,15 +335,6 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.far_cap = c.far_cap;
     A.next = d.d_next.p;
     A.max_pops = 64ull * (unsigned long long)d.W * d.H + 4096ull;
-    A.trace = nullptr;
-#ifdef FXJPS_TRACE
-    if (!d.trace) {
-        HIPCHK(h, hipHostMalloc((void**)&d.trace, (size_t)(1u << 20) * sizeof(unsigned int),
-                                hipHostMallocCoherent | hipHostMallocMapped));
-        memset(d.trace, 0, (size_t)(1u << 20) * sizeof(unsigned int));
-    }
-    A.trace = d.trace;
-#endif
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
     waves = std::max<uint32_t>(4u, (waves + 3u) & ~3u);
@@ -570,6 +590,17 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
             fxjps_destroy(h);
             return rc;
         }
+        {
+            std::vector<uint32_t> lut(11 * 256);
+            for (uint32_t pd = 0; pd < 11; pd++)
+                for (uint32_t m = 0; m < 256; m++) lut[pd * 256 + m] = dirlut_entry(pd, m);
+            e = hipMemcpyToSymbol(HIP_SYMBOL(fx::c_dirlut), lut.data(), lut.size() * sizeof(uint32_t));
+            if (e != hipSuccess) {
+                int rc = fail(nullptr, FXJPS_E_HIP, "device %d: %s", d.dev, hipGetErrorString(e));
+                fxjps_destroy(h);
+                return rc;
+            }
+        }
         d.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         d.mem_total = prop.totalGlobalMem;
     }
@@ -593,12 +624,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.comp.release();
         d.nb8.release();
         d.ci.release();
-        d.occR.release();
-        d.stopYp.release();
-        d.stopYm.release();
-        d.occC.release();
-        d.stopXp.release();
-        d.stopXm.release();
+        d.bm.release();
         for (int p = 0; p < 2; p++) {
             d.tables[p].release();
             d.far[p].release();
@@ -786,21 +812,6 @@ int fxjps_selftest_sqrt(fxjps_t* h, uint32_t n0, uint32_t n1, double* out) {
     return FXJPS_OK;
 }
 
-#ifdef FXJPS_TRACE
-// bring-up only (libfxjps_trace.so): host pointer to the progress words of device 0
-unsigned int* fxjps_debug_trace_ptr(fxjps_t* h) {
-    if (!h) return nullptr;
-    DevCtx& d = h->devs[0];
-    if (!d.trace) {
-        (void)hipSetDevice(d.dev);
-        if (hipHostMalloc((void**)&d.trace, (size_t)(1u << 20) * sizeof(unsigned int),
-                          hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
-            return nullptr;
-        memset(d.trace, 0, (size_t)(1u << 20) * sizeof(unsigned int));
-    }
-    return d.trace;
-}
-#endif
 
 // raw device counters of the last batch on device 0: [0] pops [1] pushes [2] refills [3] slow pops,
 // [8..17] per-phase cycles in FXJPS_PROF builds (tools only; not declared in fxjps.h)
