@@ -285,17 +285,17 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         // of cells/4 entries (3/4 usable) covers all of them, the retry pool covers the rest
         uint32_t l2e = ceil_log2(std::max<uint64_t>(cells / 4, 1));  // entries
         l2e = std::min(std::max(l2e, 12u), 23u);
-        c.log2_buckets = l2e - 3;
-        c.far_cap = std::max<uint32_t>(2048u, (8u << c.log2_buckets) / 16);
+        c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
+        c.far_cap = std::max<uint32_t>(2048u, ((uint32_t)fx::BUCKET << c.log2_buckets) / 16);
         c.nwaves = want_waves;
     } else {
         const uint32_t l2e = std::max(ceil_log2(cells * 2 + 64), 12u);
-        c.log2_buckets = l2e - 3;
+        c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
         c.far_cap = (uint32_t)std::min<uint64_t>(cells * 2 + 1024, 0x7FFFFFFFull);
         c.nwaves = want_waves;
     }
     // memory budget: at most 60 % of the device for one pool
-    const size_t per_wave = ((size_t)8 << c.log2_buckets) * sizeof(TEnt) + (size_t)c.far_cap * sizeof(FarEnt);
+    const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)c.far_cap * sizeof(FarEnt);
     const size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
     maxw &= ~3u;
@@ -305,12 +305,12 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     if (cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves && d.pool_clean[pool])
         return FXJPS_OK;
     if (!(cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves)) {
-        HIPCHK(h, d.tables[pool].ensure((size_t)c.nwaves * ((size_t)8 << c.log2_buckets)));
+        HIPCHK(h, d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET << c.log2_buckets)));
         HIPCHK(h, d.far[pool].ensure((size_t)c.nwaves * c.far_cap));
         cur = c;
     }
     // tables must start all-empty (key 0xFFFFFFFF); wavefronts leave them clean after each query
-    HIPCHK(h, hipMemsetAsync(d.tables[pool].p, 0xFF, (size_t)cur.nwaves * ((size_t)8 << cur.log2_buckets) * sizeof(TEnt),
+    HIPCHK(h, hipMemsetAsync(d.tables[pool].p, 0xFF, (size_t)cur.nwaves * ((size_t)fx::BUCKET << cur.log2_buckets) * sizeof(TEnt),
                              d.stream));
     d.pool_clean[pool] = true;
     return FXJPS_OK;
