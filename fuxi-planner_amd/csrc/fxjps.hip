@@ -295,7 +295,8 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         c.nwaves = want_waves;
     }
     // memory budget: at most 60 % of the device for one pool
-    const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)c.far_cap * sizeof(FarEnt);
+    c.far_cap = (c.far_cap + 7u) & ~7u;  // the u16 cell-info array behind the entries stays 16-byte granular
+    const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
     const size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
     maxw &= ~3u;
@@ -306,7 +307,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         return FXJPS_OK;
     if (!(cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves)) {
         HIPCHK(h, d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET << c.log2_buckets)));
-        HIPCHK(h, d.far[pool].ensure((size_t)c.nwaves * c.far_cap));
+        HIPCHK(h, d.far[pool].ensure((size_t)c.nwaves * (c.far_cap + c.far_cap / 8)));
         cur = c;
     }
     // tables must start all-empty (key 0xFFFFFFFF); wavefronts leave them clean after each query
