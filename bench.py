@@ -101,6 +101,12 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         algo = float(wl["algorithmic_bytes"])  # rank 0 plans exactly the committed workload
         achieved = algo / (k_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "start->goal plans/sec on 1024x1024 grid",
             "value": value,
@@ -120,9 +126,10 @@ def main():
                        "queries_per_gpu": nq, "grid": [W, H], "hchoice": hchoice,
                        "reachable": int((status > 0).sum()), "parallelism": "queries sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fx::k_search<2>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
-                         "note": "latency-bound graph search: see DESIGN.md section 4"},
+                         "note": "latency-bound graph search (DESIGN.md section 4); traffic = rocprofv3 FETCH_SIZE+WRITE_SIZE "
+                                 "bytes per launch of the profiled build (profiles/hbm_traffic.json)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             from oracle import oracle  # checker used as the CPU baseline ("port"), never by the planner
