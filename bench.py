@@ -54,16 +54,20 @@ def main():
 
     dist = None
     torch = None
+    # Bring-up aid for 1-GPU boxes (never set by the driver): FXJPS_BENCH_BACKEND=gloo runs every rank on
+    # device 0 with a host-side broadcast, to exercise the multi-rank code path without a second GPU.
+    backend = os.environ.get("FXJPS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if backend == "gloo" else local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        torch.cuda.set_device(dev_index)
+        dist.init_process_group(backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
-    planner = fx.Planner([local_rank])
+    planner = fx.Planner([dev_index])
     occ = synth.synth_grid(W, H, wl["grid_seed"], wl["p"])  # every rank needs it to draw its queries
     if world > 1:
-        sp = ShardedPlanner(planner, device="cuda:%d" % local_rank)
+        sp = ShardedPlanner(planner, device="cpu" if backend == "gloo" else "cuda:%d" % dev_index)
         sp.set_grid(occ if rank == 0 else None)  # one RCCL broadcast of W*H bytes over xGMI
     else:
         planner.set_grid_occ(occ)
@@ -90,7 +94,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda:%d" % dev_index)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if (status < 0).any():
