@@ -120,6 +120,7 @@ struct DevCtx {
     DBuf<long long> d_offsets;
     DBuf<unsigned int> d_next;
     DBuf<unsigned long long> d_counters;
+    DBuf<uint8_t> d_raw;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val;
     HBuf<int32_t> h_len, h_cells;
@@ -641,6 +642,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_offsets.release();
         d.d_next.release();
         d.d_counters.release();
+        d.d_raw.release();
         d.d_upd_xy.release();
         d.d_upd_val.release();
         d.h_len.release();
@@ -691,6 +693,99 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
     HIPCHK(h, hipMemcpyAsync(d0.occ.p, d_occ, (size_t)W * H, hipMemcpyDeviceToDevice, d0.stream));
     HIPCHK(h, hipStreamSynchronize(d0.stream));
     return finish_set_grid(h, W, H);
+}
+
+int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
+                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d) {
+    if (!h) return FXJPS_E_ARG;
+    if (!raw || !start_xy || !goal_xy || W0 < 1 || H0 < 1 || ifa < 0 || ifa > 64 || (variant != 0 && variant != 1))
+        return fail(h, FXJPS_E_ARG, "bad prepare_grid arguments");
+    const long long sx = start_xy[0], sy = start_xy[1], gx = goal_xy[0], gy = goal_xy[1];
+    // global_planner_st.py:230-235 / global_planner_ccst.py:415-420
+    long long o2x = -2ll * ifa, o2y = -2ll * ifa;
+    if (gx < 0 || sx < 0) o2x += std::min(gx, sx);
+    if (gy < 0 || sy < 0) o2y += std::min(gy, sy);
+    const long long dx = std::llabs(o2x), dy = std::llabs(o2y);
+    // :246-247 / :431-432
+    const long long W1 = std::max<long long>(std::max<long long>(W0, gx), sx) + dx + 4ll * ifa;
+    const long long H1 = std::max<long long>(std::max<long long>(H0, gy), sy) + dy + 4ll * ifa;
+    if (W1 > 8190 || H1 > 8190) return fail(h, FXJPS_E_ARG, "prepared grid %lldx%lld exceeds 8190 cells a side", W1, H1);
+    h->have_grid = false;
+    for (auto& d : h->devs) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, d.d_raw.ensure((size_t)W0 * H0));
+        int rc = alloc_grid(h, d, (int)W1, (int)H1);
+        if (rc) return rc;
+        d.pool_clean[0] = d.pool_clean[1] = false;
+        d.cfg[0] = ScratchCfg();
+        d.cfg[1] = ScratchCfg();
+        // every device pads and dilates the raw grid itself: cheaper than broadcasting the larger result
+        HIPCHK(h, hipMemcpyAsync(d.d_raw.p, raw, (size_t)W0 * H0, hipMemcpyHostToDevice, d.stream));
+        const long long n = W1 * H1;
+        hipLaunchKernelGGL(fx::k_prepare_grid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.d_raw.p, W0, H0,
+                           (int)dx, (int)dy, ifa, variant, (int)W1, (int)H1, d.occ.p);
+        HIPCHK(h, hipGetLastError());
+        rc = derive_maps(h, d);
+        if (rc) return rc;
+    }
+    for (auto& d : h->devs) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
+    }
+    h->have_grid = true;
+    // :266-267 (st: + map_d - 1) / :452-453 (ccst: + map_d)
+    const long long sh = variant == 0 ? 1 : 0;
+    long long nsx = sx + dx - sh, nsy = sy + dy - sh, ngx = gx + dx - sh, ngy = gy + dy - sh;
+    if (ngx < 0 || ngy < 0 || ngx >= W1 || ngy >= H1) return fail(h, FXJPS_E_ARG, "goal outside the prepared grid");
+    // :268-272 / :454-458: a goal on an obstacle moves to the nearest free cell of its row, else of its column
+    DevCtx& d0 = h->devs[0];
+    HIPCHK(h, hipSetDevice(d0.dev));
+    std::vector<uint8_t> row((size_t)H1), col((size_t)W1);
+    HIPCHK(h, hipMemcpy(row.data(), d0.occ.p + (size_t)ngx * H1, (size_t)H1, hipMemcpyDeviceToHost));
+    if (row[(size_t)ngy]) {
+        long long best = -1, bd = 0;
+        for (long long y = 0; y < H1; y++)
+            if (!row[(size_t)y] && (best < 0 || std::llabs(y - ngy) < bd)) {  // np.argmin: first of the nearest
+                best = y;
+                bd = std::llabs(y - ngy);
+            }
+        if (best >= 0) {
+            ngy = best;
+        } else {
+            HIPCHK(h, hipMemcpy2D(col.data(), 1, d0.occ.p + (size_t)ngy, (size_t)H1, 1, (size_t)W1, hipMemcpyDeviceToHost));
+            for (long long x = 0; x < W1; x++)
+                if (!col[(size_t)x] && (best < 0 || std::llabs(x - ngx) < bd)) {
+                    best = x;
+                    bd = std::llabs(x - ngx);
+                }
+            if (best < 0) return fail(h, FXJPS_E_ARG, "goal row and column are fully occupied (the reference raises here)");
+            ngx = best;
+        }
+    }
+    start_xy[0] = (int32_t)nsx;
+    start_xy[1] = (int32_t)nsy;
+    goal_xy[0] = (int32_t)ngx;
+    goal_xy[1] = (int32_t)ngy;
+    if (out_W) *out_W = (int32_t)W1;
+    if (out_H) *out_H = (int32_t)H1;
+    if (out_map_d) {
+        out_map_d[0] = (int32_t)dx;
+        out_map_d[1] = (int32_t)dy;
+    }
+    return FXJPS_OK;
+}
+
+int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
+    DevCtx& d = h->devs[0];
+    if (out_W) *out_W = d.W;
+    if (out_H) *out_H = d.H;
+    if (out) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, hipMemcpy(out, d.occ.p, (size_t)d.W * d.H, hipMemcpyDeviceToHost));
+    }
+    return FXJPS_OK;
 }
 
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {

@@ -81,6 +81,31 @@ class Planner(object):
         self._chk(self._L.fxjps_set_grid_device(self._h, C.c_void_p(int(dev_ptr)), int(W), int(H)))
         self.shape = (int(W), int(H))
 
+    def prepare_grid(self, raw, start, goal, ifa, variant="st"):
+        """The callers' grid preparation on the device (global_planner_st.py:230-272 / global_planner_ccst.py:415-458):
+        pad `raw` (> 0 = occupied) so that start and goal fit, dilate by `ifa`, keep the result resident.
+        -> (start', goal', map_d, (W, H)) with start'/goal' in the prepared grid (goal moved off obstacles)."""
+        raw = np.ascontiguousarray(np.asarray(raw) > 0, dtype=np.uint8)
+        if raw.ndim != 2:
+            raise ValueError("grid must be 2-D")
+        v = {"st": 0, "ccst": 1}[variant] if isinstance(variant, str) else int(variant)
+        s = (C.c_int32 * 2)(int(start[0]), int(start[1]))
+        g = (C.c_int32 * 2)(int(goal[0]), int(goal[1]))
+        W, H = C.c_int32(), C.c_int32()
+        md = (C.c_int32 * 2)()
+        self._chk(self._L.fxjps_prepare_grid(self._h, _lib.ptr(raw, C.c_uint8), raw.shape[0], raw.shape[1], int(ifa), v,
+                                             s, g, C.byref(W), C.byref(H), md))
+        self.shape = (W.value, H.value)
+        return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape
+
+    def get_grid(self):
+        """The resident uint8 [W][H] occupancy grid (e.g. the prepared map the node publishes)."""
+        W, H = C.c_int32(), C.c_int32()
+        self._chk(self._L.fxjps_get_grid(self._h, None, C.byref(W), C.byref(H)))
+        out = np.empty((W.value, H.value), dtype=np.uint8)
+        self._chk(self._L.fxjps_get_grid(self._h, _lib.ptr(out, C.c_uint8), None, None))
+        return out
+
     def update_cells(self, xy, val):
         xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
         val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)

@@ -80,6 +80,19 @@ int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H);
  * (e.g. the receive buffer of a collective the host framework ran). */
 int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H);
 
+/* Callers' grid preparation on the device -- replaces
+ * scripts/global_planner_st.py:230-272 (variant 0: dilation offsets {-ifa,0,ifa}^2, start/goal shifted by
+ * map_d - 1) and scripts/global_planner_ccst.py:415-458 (variant 1: full (2*ifa+1)^2 dilation, shift map_d):
+ * zero-pad `raw` (W0 x H0, non-zero = occupied) so that start and goal fit, dilate, make the result the
+ * resident grid, shift start_xy / goal_xy (in: cell indices relative to `raw`, may be negative; out: indices
+ * in the prepared grid) and move a goal that fell on an obstacle to the nearest free cell of its row, else of
+ * its column.  out_map_d receives the low-side padding (dx, dy). */
+int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
+                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d);
+
+/* Copy the resident grid back (out may be NULL to query the size only). */
+int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H);
+
 /* Streaming replan: set n cells (xy pairs) to val[i] (0 free / non-zero
  * obstacle) on the resident grid and rebuild the derived maps. */
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);

@@ -1,0 +1,67 @@
+"""Grid preparation: global_planner_st.py:230-272 / global_planner_ccst.py:415-458.
+Golden vectors come from executing those reference lines (tests/golden/make_golden_gridprep.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def unpack(bits_hex, shape):
+    W, H = shape
+    return np.unpackbits(np.frombuffer(bytes.fromhex(bits_hex), dtype=np.uint8))[:W * H].reshape(W, H)
+
+
+def test_oracle_restatement_matches_reference_lines():
+    from oracle import gridprep
+    recs = load_golden("gridprep.json")
+    assert len(recs) >= 200 and {r["variant"] for r in recs} == {0, 1}
+    moved = 0
+    for r in recs:
+        raw = unpack(r["raw_bits"], r["raw_shape"])
+        g, s, go, d = gridprep.prepare(raw, r["start"], r["goal"], r["ifa"], r["variant"])
+        assert list(g.shape) == r["grid_shape"] and np.array_equal(g, unpack(r["grid_bits"], r["grid_shape"]))
+        assert list(s) == r["start_out"] and list(go) == r["goal_out"] and list(d) == r["map_d"]
+        sh = 1 if r["variant"] == 0 else 0
+        moved += list(go) != [r["goal"][0] + d[0] - sh, r["goal"][1] + d[1] - sh]
+    assert moved > 20  # the goal-on-obstacle relocation is exercised
+
+
+@pytest.mark.gpu
+def test_device_grid_preparation_matches_goldens():
+    import fuxi_planner_amd as fx
+    with fx.Planner([0]) as p:
+        for r in load_golden("gridprep.json"):
+            raw = unpack(r["raw_bits"], r["raw_shape"])
+            s, g, d, shape = p.prepare_grid(raw, r["start"], r["goal"], r["ifa"], r["variant"])
+            assert list(shape) == r["grid_shape"] and list(s) == r["start_out"] and list(g) == r["goal_out"] and list(d) == r["map_d"]
+            assert np.array_equal(p.get_grid(), unpack(r["grid_bits"], r["grid_shape"]))
+
+
+@pytest.mark.gpu
+def test_prepare_then_plan_equals_host_prepared_grid(oracle):
+    """The node's tick: prepare on the device, then plan on the resident grid -- same path as planning on the
+    grid the host-side restatement prepares."""
+    from oracle import gridprep
+    import fuxi_planner_amd as fx
+    rng = np.random.default_rng(9)
+    with fx.Planner([0]) as p:
+        for it in range(30):
+            W0, H0 = int(rng.integers(20, 160)), int(rng.integers(20, 160))
+            raw = (rng.random((W0, H0)) < 0.08).astype(np.uint8)
+            start = (int(rng.integers(-3, W0)), int(rng.integers(-3, H0)))
+            goal = (int(rng.integers(0, W0 + 3)), int(rng.integers(0, H0 + 3)))
+            variant, ifa = it & 1, 1 + (it & 1)
+            try:
+                eg, es, ego, ed = gridprep.prepare(raw, start, goal, ifa, variant)
+            except (IndexError, ValueError):
+                continue
+            s, g, d, shape = p.prepare_grid(raw, start, goal, ifa, variant)
+            assert (s, g, d) == (es, ego, ed) and shape == eg.shape
+            if not (0 <= s[0] < shape[0] and 0 <= s[1] < shape[1]):
+                continue
+            off, cells, cost, st = p.plan_batch([s], [g], 2)
+            path, ocost, _ = oracle.plan(eg, s, g, 2, literal=False)
+            if path == 0:
+                assert st[0] == 0
+            else:
+                assert [tuple(map(int, c)) for c in cells] == path and cost[0] == ocost
