@@ -695,8 +695,9 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
     return finish_set_grid(h, W, H);
 }
 
-int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
-                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d) {
+static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
+                             int msg_layout, int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H,
+                             int32_t* out_map_d) {
     if (!h) return FXJPS_E_ARG;
     if (!raw || !start_xy || !goal_xy || W0 < 1 || H0 < 1 || ifa < 0 || ifa > 64 || (variant != 0 && variant != 1))
         return fail(h, FXJPS_E_ARG, "bad prepare_grid arguments");
@@ -723,7 +724,7 @@ int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, i
         HIPCHK(h, hipMemcpyAsync(d.d_raw.p, raw, (size_t)W0 * H0, hipMemcpyHostToDevice, d.stream));
         const long long n = W1 * H1;
         hipLaunchKernelGGL(fx::k_prepare_grid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.d_raw.p, W0, H0,
-                           (int)dx, (int)dy, ifa, variant, (int)W1, (int)H1, d.occ.p);
+                           (int)dx, (int)dy, ifa, variant, msg_layout, (int)W1, (int)H1, d.occ.p);
         HIPCHK(h, hipGetLastError());
         rc = derive_maps(h, d);
         if (rc) return rc;
@@ -773,6 +774,17 @@ int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, i
         out_map_d[1] = (int32_t)dy;
     }
     return FXJPS_OK;
+}
+
+int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
+                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d) {
+    return prepare_grid_impl(h, raw, W0, H0, ifa, variant, 0, start_xy, goal_xy, out_W, out_H, out_map_d);
+}
+
+int fxjps_prepare_occupancy_msg(fxjps_t* h, const int8_t* data, int32_t width, int32_t height, int32_t ifa, int32_t variant,
+                                int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d) {
+    return prepare_grid_impl(h, reinterpret_cast<const uint8_t*>(data), width, height, ifa, variant, 1, start_xy, goal_xy,
+                             out_W, out_H, out_map_d);
 }
 
 int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {

@@ -98,6 +98,22 @@ class Planner(object):
         self.shape = (W.value, H.value)
         return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape
 
+    def prepare_occupancy_msg(self, data, width, height, start, goal, ifa, variant="st"):
+        """prepare_grid straight from a nav_msgs/OccupancyGrid (`data` = msg.data, int8, row-major [y][x]):
+        map_callback (global_planner_st.py:15-20) is fused into the device kernel."""
+        data = np.ascontiguousarray(data, dtype=np.int8).reshape(-1)
+        if data.size != width * height:
+            raise ValueError("data has %d cells, expected %d" % (data.size, width * height))
+        v = {"st": 0, "ccst": 1}[variant] if isinstance(variant, str) else int(variant)
+        s = (C.c_int32 * 2)(int(start[0]), int(start[1]))
+        g = (C.c_int32 * 2)(int(goal[0]), int(goal[1]))
+        W, H = C.c_int32(), C.c_int32()
+        md = (C.c_int32 * 2)()
+        self._chk(self._L.fxjps_prepare_occupancy_msg(self._h, _lib.ptr(data, C.c_int8), int(width), int(height), int(ifa), v,
+                                                      s, g, C.byref(W), C.byref(H), md))
+        self.shape = (W.value, H.value)
+        return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape
+
     def get_grid(self):
         """The resident uint8 [W][H] occupancy grid (e.g. the prepared map the node publishes)."""
         W, H = C.c_int32(), C.c_int32()

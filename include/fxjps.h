@@ -90,6 +90,13 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H);
 int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
                        int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d);
 
+/* Same, straight from a nav_msgs/OccupancyGrid: `data` is the message's int8 data[] (row-major [y][x],
+ * width = x extent, height = y extent).  Fuses map_callback (global_planner_st.py:15-20,
+ * global_planner_ccst.py:17-23: reshape(h, w).T, 100 -> 1, -1 -> 0) into the preparation kernel. */
+int fxjps_prepare_occupancy_msg(fxjps_t* h, const int8_t* data, int32_t width, int32_t height, int32_t ifa,
+                                int32_t variant, int32_t* start_xy, int32_t* goal_xy, int32_t* out_W,
+                                int32_t* out_H, int32_t* out_map_d);
+
 /* Copy the resident grid back (out may be NULL to query the size only). */
 int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H);
 

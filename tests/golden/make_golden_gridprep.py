@@ -34,7 +34,37 @@ def run_ref(variant, raw, start, goal, ifa):
             "map_d": [int(v) for v in ns["map_d"]]}
 
 
+def run_ref_callback(msg, width, height):
+    """global_planner_st.py:16-20 (map_callback body) executed on a stand-in message object."""
+    with open(os.path.join(REF, "global_planner_st.py"), encoding="utf-8", errors="replace") as f:
+        block = textwrap.dedent("".join(f.readlines()[15:20]))
+
+    class O(object):
+        pass
+    data, self_ = O(), O()
+    data.info = O()
+    data.info.height, data.info.width, data.data = height, width, list(int(v) for v in msg)
+    exec(compile(block, "map_callback", "exec"), {"np": np, "data": data, "self": self_})
+    return self_.map
+
+
+def gen_msgs():
+    rng = np.random.default_rng(99)
+    out = []
+    for it in range(40):
+        w, h = int(rng.integers(1, 50)), int(rng.integers(1, 50))
+        msg = rng.choice(np.array([-1, 0, 0, 0, 100, 100, 1, 50, 99, -2], dtype=np.int8), size=w * h)
+        m = run_ref_callback(msg, w, h)
+        assert m.shape == (w, h)
+        out.append({"width": w, "height": h, "data": [int(v) for v in msg], "map": [int(v) for v in m.ravel()]})
+    p = os.path.join(HERE, "occupancy_msg.json")
+    with open(p, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote", p, len(out), "cases")
+
+
 def main():
+    gen_msgs()
     rng = np.random.default_rng(424242)
     out = []
     for it in range(240):

@@ -65,3 +65,34 @@ def test_prepare_then_plan_equals_host_prepared_grid(oracle):
                 assert st[0] == 0
             else:
                 assert [tuple(map(int, c)) for c in cells] == path and cost[0] == ocost
+
+
+def test_occupancy_message_goldens_are_self_consistent():
+    """map_callback (global_planner_st.py:16-20): data[y*w + x] lands at map[x][y]; 100 -> 1, -1 -> 0, the rest kept."""
+    for r in load_golden("occupancy_msg.json"):
+        w, h = r["width"], r["height"]
+        d = np.array(r["data"], dtype=np.int64).reshape(h, w).T
+        m = np.array(r["map"], dtype=np.int64).reshape(w, h)
+        exp = d.copy()
+        exp[d == 100] = 1
+        exp[d == -1] = 0
+        assert np.array_equal(m, exp)
+
+
+@pytest.mark.gpu
+def test_prepare_from_occupancy_message():
+    """The fused adapter equals map_callback followed by the grid preparation."""
+    from oracle import gridprep
+    import fuxi_planner_amd as fx
+    with fx.Planner([0]) as p:
+        for k, r in enumerate(load_golden("occupancy_msg.json")):
+            w, h = r["width"], r["height"]
+            m = np.array(r["map"], dtype=np.int64).reshape(w, h)  # what map_callback stores
+            start, goal, ifa, variant = (0, 0), (w - 1, h - 1), 1 + (k & 1), k & 1
+            try:
+                eg, es, ego, ed = gridprep.prepare(m, start, goal, ifa, variant)
+            except (IndexError, ValueError):
+                continue
+            s, g, d, shape = p.prepare_occupancy_msg(np.array(r["data"], dtype=np.int8), w, h, start, goal, ifa, variant)
+            assert (s, g, d) == (es, ego, ed) and shape == eg.shape
+            assert np.array_equal(p.get_grid(), eg)
