@@ -111,6 +111,7 @@ struct DevCtx {
     // search scratch (two pools: the regular one and the large retry one)
     DBuf<TEnt> tables[2];
     DBuf<FarEnt> far[2];
+    DBuf<uint32_t> wave_gen[2];
     ScratchCfg cfg[2];
     bool pool_clean[2] = {false, false};
     // batch buffers
@@ -309,11 +310,13 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     if (!(cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves)) {
         HIPCHK(h, d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET << c.log2_buckets)));
         HIPCHK(h, d.far[pool].ensure((size_t)c.nwaves * (c.far_cap + c.far_cap / 8)));
+        HIPCHK(h, d.wave_gen[pool].ensure((size_t)c.nwaves));
         cur = c;
     }
     // tables must start all-empty (key 0xFFFFFFFF); wavefronts leave them clean after each query
     HIPCHK(h, hipMemsetAsync(d.tables[pool].p, 0xFF, (size_t)cur.nwaves * ((size_t)fx::BUCKET << cur.log2_buckets) * sizeof(TEnt),
                              d.stream));
+    HIPCHK(h, hipMemsetAsync(d.wave_gen[pool].p, 0, (size_t)cur.nwaves * sizeof(uint32_t), d.stream));
     d.pool_clean[pool] = true;
     return FXJPS_OK;
 }
@@ -336,6 +339,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.log2_buckets = c.log2_buckets;
     A.far_cap = c.far_cap;
     A.next = d.d_next.p;
+    A.wave_gen = d.wave_gen[pool].p;
     A.max_pops = 64ull * (unsigned long long)d.W * d.H + 4096ull;
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
@@ -630,6 +634,7 @@ void fxjps_destroy(fxjps_t* h) {
         for (int p = 0; p < 2; p++) {
             d.tables[p].release();
             d.far[p].release();
+            d.wave_gen[p].release();
         }
         d.d_starts.release();
         d.d_goals.release();
