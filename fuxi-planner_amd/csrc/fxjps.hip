@@ -172,8 +172,8 @@ int fail(fxjps* h, int code, const char* fmt, ...) {
                         #call, hipGetErrorString(e__), __FILE__, __LINE__);                      \
     } while (0)
 
-// nodeNeighbours (jps1.py:49-93) on a neighbour mask: which direction each of the 8 lane groups of
-// the search kernel follows.  pd = (dX+1)*4 + (dY+1) of direction(c, came_from[c]) (jps1.py:40-47),
+// nodeNeighbours (jps1.py:49-93) on a neighbour mask: which direction each of the 8 rays of a node
+// follows in the search kernel.  pd = (dX+1)*4 + (dY+1) of direction(c, came_from[c]) (jps1.py:40-47),
 // 5 = no parent (the start node, `type(parent) != tuple`, :51).
 uint32_t dirlut_entry(uint32_t pd, uint32_t nbm) {
     auto occ = [&](int dx, int dy) -> bool { return (nbm >> fx::nbit(dx, dy)) & 1u; };
