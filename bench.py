@@ -76,7 +76,10 @@ def main():
     def sync():
         if world > 1:
             torch.cuda.synchronize()
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     def step():
         off, cells, cost, status = planner.plan_batch(starts, goals, hchoice, mpl)  # blocking: results are in host memory
