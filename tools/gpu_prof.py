@@ -19,7 +19,7 @@ names = ["pops 2..K+select", "c:wait+probe_eval", "c:write+push+reinsert", "x:di
 for nq in nqs:
     s, g = synth.synth_queries(occ, 1 if W == 1024 else 2, nq)
     for rep in range(2):
-        t = time.time(); off, cells, cost, st = p.plan_batch(s, g, 2, 1024 if W == 1024 else 4096); dt = time.time() - t
+        t = time.time(); off, cells, cost, st = p.plan_batch(s, g, int(os.environ.get("FX_HC", "2")), 1024 if W == 1024 else 4096); dt = time.time() - t
     tm = p.timing()
     c = (C.c_uint64 * 32)(); L.fxjps_debug_counters(p._h, c); c = list(c)
     print("nq=%d wall %.3fs kernel %.1f ms -> %.0f plans/s | pops %d pushes %d refills %d slow %d retried %d nopath %d" % (
