@@ -24,6 +24,10 @@ for nq in nqs:
     c = (C.c_uint64 * 32)(); L.fxjps_debug_counters(p._h, c); c = list(c)
     print("nq=%d wall %.3fs kernel %.1f ms -> %.0f plans/s | pops %d pushes %d refills %d slow %d retried %d nopath %d" % (
         nq, dt, tm["search_kernel_ms"], nq / dt, c[0], c[1], c[2], c[3], tm["retried"], int((st == 0).sum())), flush=True)
+    if c[4]:
+        print("   batches %d: popped %.2f / batch, committed %.2f / batch, general form %.2f %%" % (c[4], c[5] / c[4], c[0] / c[4], 100.0 * c[6] / c[4]), flush=True)
+    if c[4] and c[18]:
+        print("   diagonal rounds %.2f / batch, rays in flight %.1f / round" % (c[18] / c[4], c[19] / c[18]), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
