@@ -383,7 +383,8 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     HIPCHK(h, hipMemcpyAsync(d.d_starts.p, starts + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.d_goals.p, goals + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 32 * sizeof(unsigned long long), d.stream));
-    const uint32_t full = (uint32_t)d.n_cu * 32u;
+    uint32_t full = (uint32_t)d.n_cu * 32u;
+    if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(4, atoi(e)) & ~3u;  // measurement aid
     // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
     // on the config-2 workload), so far-apart queries are handed out first and the short ones fill
     // the tail.  Counting sort on the Chebyshev distance, descending.
