@@ -15,7 +15,8 @@ BACKEND_HIP = 1
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_update_cells", "fxjps_plan_batch",
-           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_debug_read_nbmask")
+           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_debug_read_nbmask",
+           "fxjps_waypoint_st", "fxjps_waypoint_ccst")
 
 
 class Timing(C.Structure):
@@ -82,6 +83,11 @@ def load():
     L.fxjps_selftest_wavemin.argtypes = [vp, C.c_int32, C.c_uint64, p_i64]
     L.fxjps_debug_read_nbmask.restype = C.c_int
     L.fxjps_debug_read_nbmask.argtypes = [vp, p_u8]
+    L.fxjps_waypoint_st.restype = C.c_int
+    L.fxjps_waypoint_st.argtypes = [p_i32, C.c_int32, p_i32, C.c_double, p_f64, p_f64, p_f64, C.c_int32, C.c_double, C.c_double,
+                                    p_f64, C.c_int32, p_f64, p_i32, p_f64, p_f64]
+    L.fxjps_waypoint_ccst.restype = C.c_int
+    L.fxjps_waypoint_ccst.argtypes = [p_i32, C.c_int32, p_u8, C.c_int32, C.c_int32, C.c_double, p_f64, p_f64, p_f64, p_f64, p_i32, p_i32]
     _lib = L
     return L
 

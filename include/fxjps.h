@@ -156,6 +156,25 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
  * (W+2)x(H+2) neighbour-mask bytes.  buf must hold (W+2)*(H+2) bytes. */
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
 
+/* ---- Waypoint selection after a plan.  Host functions (no device work, no handle):
+ * the step the reference's nodes run on the path jps1.method returned.  `cells` are the n (x, y) jump points of
+ * one query as fxjps_plan_batch(_csr) returns them.
+ *
+ * fxjps_waypoint_st: scripts/global_planner_st.py:292-327 (angle / distance rule).  map_start is the shifted start
+ * of the tick, prev_wp the waypoint left over from the previous tick (NULL: None; prev_dim 2 or 3 components) --
+ * the reference keeps it when the loop does not pick a new one.  out_wp has out_dim (2 or 3) valid components,
+ * out_goal is global_goal after the block (it becomes the vehicle position when end_occu == 1), out_ang_wp ang_wp.
+ *
+ * fxjps_waypoint_ccst: scripts/global_planner_ccst.py:487-526 with map_line_col (:258-283): points closer than
+ * 1.5 to the vehicle are dropped, then every point whose neighbours see each other on the grid (occ, uint8 [W][H],
+ * obstacle iff == 1: the matrix the search ran on); the waypoint is the 1.4 / 0.6 blend of the second and third
+ * remaining points, or the goal.  kept_cells (2 * n int32, optional) / n_kept receive the remaining cells. */
+int fxjps_waypoint_st(const int32_t* cells, int32_t n, const int32_t* map_start, double reso, const double* origin, const double* pos,
+                      const double* goal, int32_t end_occu, double dis_wp_tre, double ang_wp_tre, const double* prev_wp,
+                      int32_t prev_dim, double* out_wp, int32_t* out_dim, double* out_goal, double* out_ang_wp);
+int fxjps_waypoint_ccst(const int32_t* cells, int32_t n, const uint8_t* occ, int32_t W, int32_t H, double reso, const double* origin,
+                        const double* pos, const double* goal, double* out_wp, int32_t* kept_cells, int32_t* n_kept);
+
 #ifdef __cplusplus
 }
 #endif

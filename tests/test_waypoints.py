@@ -1,0 +1,69 @@
+"""Waypoint post-processing against vectors produced by executing the reference's own lines
+(tests/golden/make_golden_waypoints.py: global_planner_st.py:292-327, global_planner_ccst.py:487-526 + :258-283).
+Host functions of the C ABI: no GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fuxi_planner_amd as fx
+from fuxi_planner_amd import waypoints
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def cases():
+    with open(os.path.join(HERE, "golden", "waypoints.json")) as f:
+        return json.load(f)
+
+
+def grid_of(rec):
+    bits = np.unpackbits(np.frombuffer(bytes.fromhex(rec["occ_bits"]), dtype=np.uint8))[:rec["W"] * rec["H"]]
+    return bits.reshape(rec["W"], rec["H"]).astype(np.uint8)
+
+
+def test_st_rule_matches_reference_lines():
+    n = 0
+    for rec in cases():
+        if rec["variant"] != 0:
+            continue
+        wp, goal, ang = waypoints.select_st(rec["path"], rec["map_start"], rec["reso"], rec["origin"], rec["pos"], rec["goal"],
+                                            rec["end_occu"], rec["prev_wp"])
+        exp = rec["out"]
+        assert wp.tolist() == exp["wp"], (n, wp, exp["wp"])           # bit-exact, including the number of components
+        assert goal.tolist() == exp["goal_out"]
+        assert ang == exp["ang_wp"]
+        n += 1
+    assert n == 150
+
+
+def test_ccst_pruning_matches_reference_lines():
+    n = pruned = 0
+    for rec in cases():
+        if rec["variant"] != 1:
+            continue
+        wp, kept = waypoints.select_ccst(rec["path"], grid_of(rec), rec["reso"], rec["origin"], rec["pos"], rec["goal"])
+        exp = rec["out"]
+        assert kept.tolist() == exp["kept"], (n, kept.tolist(), exp["kept"])
+        assert wp.tolist() == exp["wp"], (n, wp, exp["wp"])
+        pruned += len(exp["kept"]) < len(rec["path"])
+        n += 1
+    assert n == 150 and pruned > 100
+
+
+def test_edge_cases():
+    occ = np.zeros((10, 10), dtype=np.uint8)
+    # a single-cell path (start == goal): nothing to prune, the waypoint is the goal
+    wp, kept = waypoints.select_ccst([(3, 3)], occ, 0.2, (0.0, 0.0), (0.0, 0.0, 1.0), (5.0, 5.0, 1.5))
+    assert wp.tolist() == [5.0, 5.0, 1.5] and kept.tolist() == [[3, 3]]
+    wp, goal, ang = waypoints.select_st([(3, 3)], (4, 4), 0.2, (0.0, 0.0), (0.0, 0.0, 1.0), (5.0, 5.0, 1.5))
+    assert wp.tolist() == [5.0, 5.0, 1.5] and ang == 0.0
+    # vertical segment (equal x): the reference's slope is a division by zero it never uses
+    occ[4, 5] = 1
+    wp, kept = waypoints.select_ccst([(4, 0), (4, 4), (4, 9)], occ, 1.0, (0.0, 0.0), (100.0, 100.0, 0.0), (9.0, 9.0, 1.0))
+    assert kept.tolist() == [[4, 0], [4, 9]]
+    with pytest.raises(ValueError):
+        waypoints.select_ccst([], occ, 1.0, (0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    with pytest.raises(fx.FxjpsError):
+        waypoints.select_ccst([(-1, 2)], occ, 1.0, (0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
