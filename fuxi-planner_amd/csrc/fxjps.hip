@@ -302,9 +302,10 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
     const size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
-    maxw &= ~3u;
-    if (maxw < 4) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
-    c.nwaves = std::max(4u, std::min(c.nwaves & ~3u, maxw));
+    constexpr uint32_t WPBm = (uint32_t)fx::WPB - 1u;  // wavefront counts are whole blocks
+    maxw &= ~WPBm;
+    if (maxw < (uint32_t)fx::WPB) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
+    c.nwaves = std::max((uint32_t)fx::WPB, std::min((c.nwaves + WPBm) & ~WPBm, maxw));
     ScratchCfg& cur = d.cfg[pool];
     if (cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves && d.pool_clean[pool])
         return FXJPS_OK;
@@ -344,7 +345,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.max_pops = 64ull * (unsigned long long)d.W * d.H + 4096ull;
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
-    waves = std::max<uint32_t>(4u, (waves + 3u) & ~3u);
+    waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
     waves = std::min<uint32_t>(waves, c.nwaves);
     const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
@@ -384,8 +385,8 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     HIPCHK(h, hipMemcpyAsync(d.d_starts.p, starts + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.d_goals.p, goals + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 32 * sizeof(unsigned long long), d.stream));
-    uint32_t full = (uint32_t)d.n_cu * 32u;
-    if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(4, atoi(e)) & ~3u;  // measurement aid
+    uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC;  // every wavefront the chip can hold at once
+    if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(fx::WPB, atoi(e)) & ~((uint32_t)fx::WPB - 1u);  // measurement aid
     // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
     // on the config-2 workload), so far-apart queries are handed out first and the short ones fill
     // the tail.  Counting sort on the Chebyshev distance, descending.
