@@ -98,6 +98,12 @@ class Planner(object):
         self.shape = (W.value, H.value)
         return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape
 
+    @staticmethod
+    def shifted_origin(map_o, map_d, map_reso):
+        """The map origin after the preparation (global_planner_st.py:235-236 / global_planner_ccst.py:420-421): the
+        padding moves it by -map_d cells.  Same expression, same rounding, as the reference's."""
+        return list(-np.asarray(map_d) * map_reso + np.asarray(map_o, dtype=np.float64))
+
     def prepare_occupancy_msg(self, data, width, height, start, goal, ifa, variant="st"):
         """prepare_grid straight from a nav_msgs/OccupancyGrid (`data` = msg.data, int8, row-major [y][x]):
         map_callback (global_planner_st.py:15-20) is fused into the device kernel."""
