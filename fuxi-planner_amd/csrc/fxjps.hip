@@ -943,7 +943,7 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
     if (!h || !mismatches || rounds < 1 || rounds > (1 << 16)) return FXJPS_E_ARG;
     DevCtx& d = h->devs[0];
     HIPCHK(h, hipSetDevice(d.dev));
-    std::vector<uint64_t> in((size_t)rounds * 64), out((size_t)rounds * 4);
+    std::vector<uint64_t> in((size_t)rounds * 64), out((size_t)rounds * 4 + (size_t)rounds * 32);  // minima, then u32 ranks
     uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
     for (size_t i = 0; i < in.size(); i++) {
         x ^= x << 13;
@@ -974,6 +974,17 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
             m32 = std::min(m32, (uint32_t)(in[(size_t)r * 64 + l] >> 7));
         }
         if (out[(size_t)r * 4] != m64 || out[(size_t)r * 4 + 1] != m64 || out[(size_t)r * 4 + 2] != m32 || out[(size_t)r * 4 + 3] != m32) bad++;
+        // wave_rank64: number of lanes with a smaller key
+        const uint32_t* rk = reinterpret_cast<const uint32_t*>(out.data() + (size_t)rounds * 4) + (size_t)r * 64;
+        for (int l = 0; l < 64; l++) {
+            const uint32_t k = (uint32_t)(in[(size_t)r * 64 + l] >> 7);
+            uint32_t c = 0;
+            for (int m = 0; m < 64; m++) c += ((uint32_t)(in[(size_t)r * 64 + m] >> 7) < k) ? 1u : 0u;
+            if (rk[l] != c) {
+                bad++;
+                break;
+            }
+        }
     }
     *mismatches = bad;
     return FXJPS_OK;
