@@ -15,7 +15,7 @@ L = _lib.load()
 L.fxjps_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 occ = synth.synth_grid(W, W, 1 if W == 1024 else 2, 0.20)
 p.set_grid_occ(occ)
-names = ["pops 2..K+select", "c:wait+probe_eval", "c:write+push+reinsert", "x:dirs+issue", "x:eval+diag", "x:more+bcast", "c:math+nvalid", "c:hazard", "pop 1 (+refill)", "looptop"]
+names = ["take batch", "c:wait+probe_eval", "c:write+push+merge", "x:dirs+issue", "x:eval+diag", "x:more+bcast", "c:math+nvalid", "c:hazard", "R/M/far refills", "looptop"]
 for nq in nqs:
     s, g = synth.synth_queries(occ, 1 if W == 1024 else 2, nq)
     for rep in range(2):
