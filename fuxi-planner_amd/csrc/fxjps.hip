@@ -287,6 +287,17 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         // on average, 117 k at p99, 139 k at most, and keeps at most 2.4 k entries open; a table
         // of cells/4 entries (3/4 usable) covers all of them, the retry pool covers the rest
         uint32_t l2e = ceil_log2(std::max<uint64_t>(cells / 4, 1));  // entries
+        // ... and up to four times that when a full set of wavefronts still fits in 40 % of the device: the hardest
+        // queries fill half of a cells/4 table, where one 4-slot bucket in seven is full and the node that meets it
+        // is committed by the slow general form (config 2: 152.9 -> 146.9 ms per 10 000 queries).
+        {
+            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC;
+            const uint64_t cap = d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30);
+            uint32_t shift = 2;
+            if (const char* e = getenv("FXJPS_TABLE_SHIFT")) shift = (uint32_t)std::max(0, atoi(e));  // measurement aid
+            while (shift > 0 && full * (((uint64_t)17 << (l2e + shift))) > cap) shift--;  // 16-byte entries + far tier
+            l2e += shift;
+        }
         l2e = std::min(std::max(l2e, 12u), 23u);
         c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
         c.far_cap = std::max<uint32_t>(2048u, ((uint32_t)fx::BUCKET << c.log2_buckets) / 16);
