@@ -31,7 +31,7 @@ for nq in nqs:
     if c[4] and c[20]:
         print("   R refills: one per %.1f batches, %.1f entries each, %.2f aiming rounds each, exact sort in %.1f %%" % (c[4] / c[20], c[23] / c[20], c[21] / c[20], 100.0 * c[22] / c[20]), flush=True)
     if c[4]:
-        print("   nodes of a batch not committed: %.2f key rule, %.2f goal/parent/bucket, %.2f shared slot" % (c[24] / c[4], c[25] / c[4], c[26] / c[4]), flush=True)
+        print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
