@@ -295,12 +295,12 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
             const uint64_t cap = d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30);
             uint32_t shift = 2;
             if (const char* e = getenv("FXJPS_TABLE_SHIFT")) shift = (uint32_t)std::max(0, atoi(e));  // measurement aid
-            while (shift > 0 && full * (((uint64_t)17 << (l2e + shift))) > cap) shift--;  // 16-byte entries + far tier
+            while (shift > 0 && full * (((uint64_t)19 << (l2e + shift))) > cap) shift--;  // 16-byte entries + the far tier (an eighth as many 18-byte entries)
             l2e += shift;
         }
         l2e = std::min(std::max(l2e, 12u), 23u);
         c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
-        c.far_cap = std::max<uint32_t>(2048u, ((uint32_t)fx::BUCKET << c.log2_buckets) / 16);
+        c.far_cap = std::max<uint32_t>(2048u, ((uint32_t)fx::BUCKET << c.log2_buckets) / 8);
         c.nwaves = want_waves;
     } else {
         const uint32_t l2e = std::max(ceil_log2(cells * 2 + 64), 12u);
