@@ -122,7 +122,7 @@ struct DevCtx {
     DBuf<long long> d_offsets;
     DBuf<unsigned int> d_next;
     DBuf<unsigned long long> d_counters;
-    DBuf<uint8_t> d_raw;
+    DBuf<uint8_t> d_raw, d_img;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val;
     HBuf<int32_t> h_len, h_cells;
@@ -308,22 +308,45 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         c.far_cap = (uint32_t)std::min<uint64_t>(cells * 2 + 1024, 0x7FFFFFFFull);
         c.nwaves = want_waves;
     }
-    // memory budget: at most 60 % of the device for one pool
     c.far_cap = (c.far_cap + 7u) & ~7u;  // the u16 cell-info array behind the entries stays 16-byte granular
     const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
-    const size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
+    // Memory budget.  Pool 0 may take 60 % of the device; pool 1 (allocated while pool 0 stays resident) is sized
+    // from what is free right now plus what it already holds, so that the two pools share one budget.
+    size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
+    if (pool == 1) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t held = d.tables[1].cap * sizeof(TEnt) + d.far[1].cap * sizeof(FarEnt);
+            budget = std::min(budget, (size_t)((free_b + held) * 0.9));
+        }
+    }
+    if (const char* e = getenv("FXJPS_POOL_BUDGET_MB")) budget = std::min<size_t>(budget, (size_t)std::max(1, atoi(e)) << 20);  // test aid
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
     constexpr uint32_t WPBm = (uint32_t)fx::WPB - 1u;  // wavefront counts are whole blocks
     maxw &= ~WPBm;
     if (maxw < (uint32_t)fx::WPB) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
     c.nwaves = std::max((uint32_t)fx::WPB, std::min((c.nwaves + WPBm) & ~WPBm, maxw));
     ScratchCfg& cur = d.cfg[pool];
-    if (cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves && d.pool_clean[pool])
-        return FXJPS_OK;
-    if (!(cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves)) {
-        HIPCHK(h, d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET << c.log2_buckets)));
-        HIPCHK(h, d.far[pool].ensure((size_t)c.nwaves * (c.far_cap + c.far_cap / 8)));
-        HIPCHK(h, d.wave_gen[pool].ensure((size_t)c.nwaves));
+    const bool same = cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
+    if (same && d.pool_clean[pool]) return FXJPS_OK;
+    if (!same) {
+        // the old buffers die inside ensure(): forget the old configuration first, so that a failed allocation can
+        // never leave a stale cfg pointing at freed (or never wiped) memory
+        cur = ScratchCfg();
+        d.pool_clean[pool] = false;
+        for (;;) {  // on out-of-memory run with fewer resident wavefronts instead of failing the batch
+            hipError_t e = d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET << c.log2_buckets));
+            if (e == hipSuccess) e = d.far[pool].ensure((size_t)c.nwaves * (c.far_cap + c.far_cap / 8));
+            if (e == hipSuccess) e = d.wave_gen[pool].ensure((size_t)c.nwaves);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            d.tables[pool].release();
+            d.far[pool].release();
+            if (e != hipErrorOutOfMemory || c.nwaves <= (uint32_t)fx::WPB)
+                return fail(h, e == hipErrorOutOfMemory ? FXJPS_E_NOMEM : FXJPS_E_HIP, "scratch pool %d: %s", pool, hipGetErrorString(e));
+            c.nwaves = std::max((uint32_t)fx::WPB, (c.nwaves / 2u) & ~WPBm);
+            DBG("pool %d: out of memory, retrying with %u wavefronts", pool, c.nwaves);
+        }
         cur = c;
     }
     // tables must start all-empty (key 0xFFFFFFFF); wavefronts leave them clean after each query
@@ -493,13 +516,20 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
         h->devs[r].q0 = nq * r / nd;
         h->devs[r].nq = nq * (r + 1) / nd - h->devs[r].q0;
     }
-    for (int r = 0; r < nd; r++) {
-        int rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
-        if (rc) return rc;
-    }
-    for (int r = 0; r < nd; r++) {
-        int rc = finish_shard(h, h->devs[r], hchoice, max_len);
-        if (rc) return rc;
+    int rc = FXJPS_OK;
+    for (int r = 0; r < nd && !rc; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
+    for (int r = 0; r < nd && !rc; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
+    if (rc) {
+        // copies and kernels of the other devices may still be in flight on the caller's buffers and on device
+        // buffers the next call may reallocate: drain every stream before the error leaves the library
+        const std::string keep = h->err;
+        for (auto& d : h->devs) {
+            if (hipSetDevice(d.dev) == hipSuccess) (void)hipStreamSynchronize(d.stream);
+            d.pool_clean[0] = d.pool_clean[1] = false;  // a search may have died half-way through a table
+        }
+        (void)hipGetLastError();
+        h->err = keep;
+        return rc;
     }
     fxjps_timing_t& T = h->timing;
     T.search_kernel_ms = 0;
@@ -575,7 +605,7 @@ int finish_set_grid(fxjps* h, int W, int H) {
 
 extern "C" {
 
-int fxjps_version(void) { return 100; }
+int fxjps_version(void) { return 200; }
 
 int fxjps_device_count(void) {
     int n = 0;
@@ -662,6 +692,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_next.release();
         d.d_counters.release();
         d.d_raw.release();
+        d.d_img.release();
         d.d_upd_xy.release();
         d.d_upd_val.release();
         d.h_len.release();
@@ -716,7 +747,7 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
 
 static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
                              int msg_layout, int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H,
-                             int32_t* out_map_d) {
+                             int32_t* out_map_d, int32_t* out_end_occu) {
     if (!h) return FXJPS_E_ARG;
     if (!raw || !start_xy || !goal_xy || W0 < 1 || H0 < 1 || ifa < 0 || ifa > 64 || (variant != 0 && variant != 1))
         return fail(h, FXJPS_E_ARG, "bad prepare_grid arguments");
@@ -762,7 +793,9 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
     HIPCHK(h, hipSetDevice(d0.dev));
     std::vector<uint8_t> row((size_t)H1), col((size_t)W1);
     HIPCHK(h, hipMemcpy(row.data(), d0.occ.p + (size_t)ngx * H1, (size_t)H1, hipMemcpyDeviceToHost));
+    int32_t end_occu = 0;
     if (row[(size_t)ngy]) {
+        if (variant == 0) end_occu = 1;  // st:273
         long long best = -1, bd = 0;
         for (long long y = 0; y < H1; y++)
             if (!row[(size_t)y] && (best < 0 || std::llabs(y - ngy) < bd)) {  // np.argmin: first of the nearest
@@ -782,6 +815,20 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
             ngx = best;
         }
     }
+    if (variant == 1 && ifa > 0) {
+        // ccst:461-464: end_occu = (mapu[gx-ifa:gx+ifa, gy-ifa:gy+ifa] == 1).any() around the (moved) goal, with
+        // numpy's slice rules: a negative bound counts from the end, everything is clipped to the array
+        auto bound = [](long long v, long long n) { return v < 0 ? std::max<long long>(v + n, 0) : std::min(v, n); };
+        const long long x0 = bound(ngx - ifa, W1), x1 = bound(ngx + ifa, W1), y0 = bound(ngy - ifa, H1), y1 = bound(ngy + ifa, H1);
+        if (x1 > x0 && y1 > y0) {
+            std::vector<uint8_t> box((size_t)((x1 - x0) * (y1 - y0)));
+            HIPCHK(h, hipMemcpy2D(box.data(), (size_t)(y1 - y0), d0.occ.p + (size_t)x0 * H1 + (size_t)y0, (size_t)H1, (size_t)(y1 - y0),
+                                  (size_t)(x1 - x0), hipMemcpyDeviceToHost));
+            for (uint8_t v : box)
+                if (v) end_occu = 1;
+        }
+    }
+    if (out_end_occu) *out_end_occu = end_occu;
     start_xy[0] = (int32_t)nsx;
     start_xy[1] = (int32_t)nsy;
     goal_xy[0] = (int32_t)ngx;
@@ -796,14 +843,16 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
 }
 
 int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
-                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d) {
-    return prepare_grid_impl(h, raw, W0, H0, ifa, variant, 0, start_xy, goal_xy, out_W, out_H, out_map_d);
+                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d,
+                       int32_t* out_end_occu) {
+    return prepare_grid_impl(h, raw, W0, H0, ifa, variant, 0, start_xy, goal_xy, out_W, out_H, out_map_d, out_end_occu);
 }
 
 int fxjps_prepare_occupancy_msg(fxjps_t* h, const int8_t* data, int32_t width, int32_t height, int32_t ifa, int32_t variant,
-                                int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d) {
+                                int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d,
+                                int32_t* out_end_occu) {
     return prepare_grid_impl(h, reinterpret_cast<const uint8_t*>(data), width, height, ifa, variant, 1, start_xy, goal_xy,
-                             out_W, out_H, out_map_d);
+                             out_W, out_H, out_map_d, out_end_occu);
 }
 
 int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {
@@ -816,6 +865,74 @@ int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {
         HIPCHK(h, hipSetDevice(d.dev));
         HIPCHK(h, hipMemcpy(out, d.occ.p, (size_t)d.W * d.H, hipMemcpyDeviceToHost));
     }
+    return FXJPS_OK;
+}
+
+// ------------------------------------------------------------------ wire / on-disk adapters
+namespace {
+// dst[(fb ? B-1-b : b)][(fa ? A-1-a : a)][0..ch) = map(src[a][b]) for src [A][B], dst [B][A][ch]
+int transpose_map(fxjps_t* h, DevCtx& d, const uint8_t* d_src, int A, int B, int fa, int fb, int mode, int ch, uint8_t* d_dst) {
+    const dim3 grid((unsigned)((B + 31) / 32), (unsigned)((A + 31) / 32)), block(32, 8);
+    hipLaunchKernelGGL(fx::k_transpose_map, grid, block, 0, d.stream, d_src, A, B, fa, fb, mode, ch, d_dst);
+    HIPCHK(h, hipGetLastError());
+    return FXJPS_OK;
+}
+}  // namespace
+
+int fxjps_publish_map(fxjps_t* h, int8_t* out_data, int32_t* out_width, int32_t* out_height) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
+    DevCtx& d = h->devs[0];
+    if (out_width) *out_width = d.W;    // info.width  = len(data)      global_planner_st.py:109
+    if (out_height) *out_height = d.H;  // info.height = len(data[0])   :110
+    if (!out_data) return FXJPS_OK;
+    HIPCHK(h, hipSetDevice(d.dev));
+    const size_t n = (size_t)d.W * d.H;
+    HIPCHK(h, d.d_img.ensure(n));
+    int rc = transpose_map(h, d, d.occ.p, d.W, d.H, 0, 0, fx::TM_OCC_TO_MSG, 1, d.d_img.p);  // data.T, 1 -> 100   :103,115
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out_data, d.d_img.p, n, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
+    return FXJPS_OK;
+}
+
+int fxjps_set_grid_image(fxjps_t* h, const uint8_t* gray, int32_t rows, int32_t cols) {
+    if (!h) return FXJPS_E_ARG;
+    if (!gray || rows < 1 || cols < 1 || rows > 8190 || cols > 8190) return fail(h, FXJPS_E_ARG, "image must be 1..8190 pixels a side");
+    h->have_grid = false;
+    const size_t n = (size_t)rows * cols;
+    for (auto& d : h->devs) {
+        int rc = alloc_grid(h, d, cols, rows);  // map_pre = img[::-1].T: W = image columns, H = image rows   :182
+        if (rc) return rc;
+        d.pool_clean[0] = d.pool_clean[1] = false;
+        d.cfg[0] = ScratchCfg();
+        d.cfg[1] = ScratchCfg();
+    }
+    DevCtx& d0 = h->devs[0];
+    HIPCHK(h, hipSetDevice(d0.dev));
+    HIPCHK(h, d0.d_img.ensure(n));
+    HIPCHK(h, hipMemcpyAsync(d0.d_img.p, gray, n, hipMemcpyHostToDevice, d0.stream));
+    int rc = transpose_map(h, d0, d0.d_img.p, rows, cols, 1, 0, fx::TM_GRAY_TO_OCC, 1, d0.occ.p);  // > 200 white/free, else black/occupied   :179-180
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(d0.stream));
+    return finish_set_grid(h, cols, rows);
+}
+
+int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* out_rows, int32_t* out_cols) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
+    if (channels != 1 && channels != 3) return fail(h, FXJPS_E_ARG, "channels must be 1 (L) or 3 (RGB)");
+    DevCtx& d = h->devs[0];
+    if (out_rows) *out_rows = d.H;  // mapsave.T[::-1]: rows = y extent, top row = largest y   :370
+    if (out_cols) *out_cols = d.W;
+    if (!out) return FXJPS_OK;
+    HIPCHK(h, hipSetDevice(d.dev));
+    const size_t n = (size_t)d.W * d.H * channels;
+    HIPCHK(h, d.d_img.ensure(n));
+    int rc = transpose_map(h, d, d.occ.p, d.W, d.H, 0, 1, fx::TM_OCC_TO_GRAY, channels, d.d_img.p);  // 0 -> 255, else 0   :368-369
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, d.d_img.p, n, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
     return FXJPS_OK;
 }
 
@@ -1094,7 +1211,8 @@ bool line_is_free(const uint8_t* occ, int32_t W, int32_t H, const int32_t* a, co
 }  // namespace
 
 int fxjps_waypoint_ccst(const int32_t* cells, int32_t n, const uint8_t* occ, int32_t W, int32_t H, double reso, const double* origin,
-                        const double* pos, const double* goal, double* out_wp, int32_t* kept_cells, int32_t* n_kept) {
+                        const double* pos, const double* goal, int32_t end_occu, double* out_wp, double* out_goal,
+                        int32_t* kept_cells, int32_t* n_kept) {
     if (!cells || n < 1 || !occ || W < 1 || H < 1 || !origin || !pos || !goal || !out_wp) return FXJPS_E_ARG;
     for (int i = 0; i < n; i++)
         if (cells[2 * i] < 0 || cells[2 * i + 1] < 0) return FXJPS_E_ARG;
@@ -1138,6 +1256,14 @@ int fxjps_waypoint_ccst(const int32_t* cells, int32_t n, const uint8_t* occ, int
         for (int k = 0; k < 3; k++) out_wp[k] = (p4[3 + k] * 1.4 + p4[6 + k] * 0.6) / 2;
     } else {
         for (int k = 0; k < 3; k++) out_wp[k] = goal[k];
+    }
+    if (out_goal)
+        for (int k = 0; k < 3; k++) out_goal[k] = goal[k];
+    if (end_occu == 1) {  // :541-544: the goal region is occupied: hold position, the vehicle position becomes the goal
+        for (int k = 0; k < 3; k++) {
+            out_wp[k] = pos[k];
+            if (out_goal) out_goal[k] = pos[k];
+        }
     }
     if (kept_cells)
         for (int i = 0; i < 2 * m; i++) kept_cells[i] = c2[i];

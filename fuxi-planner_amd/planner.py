@@ -84,19 +84,20 @@ class Planner(object):
     def prepare_grid(self, raw, start, goal, ifa, variant="st"):
         """The callers' grid preparation on the device (global_planner_st.py:230-272 / global_planner_ccst.py:415-458):
         pad `raw` (> 0 = occupied) so that start and goal fit, dilate by `ifa`, keep the result resident.
-        -> (start', goal', map_d, (W, H)) with start'/goal' in the prepared grid (goal moved off obstacles)."""
+        -> (start', goal', map_d, (W, H), end_occu) with start'/goal' in the prepared grid (goal moved off obstacles)
+        and the reference's end_occu flag (global_planner_st.py:268-275 / global_planner_ccst.py:461-464)."""
         raw = np.ascontiguousarray(np.asarray(raw) > 0, dtype=np.uint8)
         if raw.ndim != 2:
             raise ValueError("grid must be 2-D")
         v = {"st": 0, "ccst": 1}[variant] if isinstance(variant, str) else int(variant)
         s = (C.c_int32 * 2)(int(start[0]), int(start[1]))
         g = (C.c_int32 * 2)(int(goal[0]), int(goal[1]))
-        W, H = C.c_int32(), C.c_int32()
+        W, H, eo = C.c_int32(), C.c_int32(), C.c_int32()
         md = (C.c_int32 * 2)()
         self._chk(self._L.fxjps_prepare_grid(self._h, _lib.ptr(raw, C.c_uint8), raw.shape[0], raw.shape[1], int(ifa), v,
-                                             s, g, C.byref(W), C.byref(H), md))
+                                             s, g, C.byref(W), C.byref(H), md, C.byref(eo)))
         self.shape = (W.value, H.value)
-        return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape
+        return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape, eo.value
 
     @staticmethod
     def shifted_origin(map_o, map_d, map_reso):
@@ -113,12 +114,12 @@ class Planner(object):
         v = {"st": 0, "ccst": 1}[variant] if isinstance(variant, str) else int(variant)
         s = (C.c_int32 * 2)(int(start[0]), int(start[1]))
         g = (C.c_int32 * 2)(int(goal[0]), int(goal[1]))
-        W, H = C.c_int32(), C.c_int32()
+        W, H, eo = C.c_int32(), C.c_int32(), C.c_int32()
         md = (C.c_int32 * 2)()
         self._chk(self._L.fxjps_prepare_occupancy_msg(self._h, _lib.ptr(data, C.c_int8), int(width), int(height), int(ifa), v,
-                                                      s, g, C.byref(W), C.byref(H), md))
+                                                      s, g, C.byref(W), C.byref(H), md, C.byref(eo)))
         self.shape = (W.value, H.value)
-        return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape
+        return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape, eo.value
 
     def get_grid(self):
         """The resident uint8 [W][H] occupancy grid (e.g. the prepared map the node publishes)."""
@@ -126,6 +127,33 @@ class Planner(object):
         self._chk(self._L.fxjps_get_grid(self._h, None, C.byref(W), C.byref(H)))
         out = np.empty((W.value, H.value), dtype=np.uint8)
         self._chk(self._L.fxjps_get_grid(self._h, _lib.ptr(out, C.c_uint8), None, None))
+        return out
+
+    # -- wire / on-disk adapters
+    def publish_map(self):
+        """What publish_map (global_planner_st.py:102-115) sends: -> (data int8[W*H] row-major [y][x] with 100 = occupied,
+        width, height) of the resident grid."""
+        w, h = C.c_int32(), C.c_int32()
+        self._chk(self._L.fxjps_publish_map(self._h, None, C.byref(w), C.byref(h)))
+        data = np.empty(w.value * h.value, dtype=np.int8)
+        self._chk(self._L.fxjps_publish_map(self._h, _lib.ptr(data, C.c_int8), None, None))
+        return data, w.value, h.value
+
+    def set_grid_image(self, gray):
+        """Adopt a decoded 8-bit grey image (rows x cols) as the resident grid with the prior-map convention of
+        global_planner_st.py:176-182: > 200 free, else occupied, grid = img[::-1].T."""
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        if gray.ndim != 2:
+            raise ValueError("image must be 2-D (convert('L'))")
+        self._chk(self._L.fxjps_set_grid_image(self._h, _lib.ptr(gray, C.c_uint8), gray.shape[0], gray.shape[1]))
+        self.shape = (gray.shape[1], gray.shape[0])
+
+    def snapshot_image(self, channels=1):
+        """The snapshot convention of global_planner_st.py:365-374: uint8 [H][W] (or [H][W][3]) image, 255 = free."""
+        r, c = C.c_int32(), C.c_int32()
+        self._chk(self._L.fxjps_snapshot_image(self._h, None, int(channels), C.byref(r), C.byref(c)))
+        out = np.empty((r.value, c.value) if channels == 1 else (r.value, c.value, channels), dtype=np.uint8)
+        self._chk(self._L.fxjps_snapshot_image(self._h, _lib.ptr(out, C.c_uint8), int(channels), None, None))
         return out
 
     def update_cells(self, xy, val):

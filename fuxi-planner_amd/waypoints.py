@@ -7,7 +7,8 @@ host code and need no device.
     if path1[0] is not 0:
         wp, global_goal, ang_wp = waypoints.select_st(path1[0], map_start, map_reso, map_o, (px, py, pz), global_goal,
                                                       end_occu, prev_wp=wp)                          # st
-        wp, kept = waypoints.select_ccst(path1[0], mapu, map_reso, map_o, (px, py, pz), global_goal)   # ccst
+        wp, kept, global_goal = waypoints.select_ccst(path1[0], mapu, map_reso, map_o, (px, py, pz), global_goal,
+                                                      end_occu, return_goal=True)                  # ccst
 """
 import ctypes as C
 import math
@@ -53,18 +54,22 @@ def select_st(path, map_start, map_reso, map_o, pos, global_goal, end_occu=0, pr
     return wp[:dim.value].copy(), gout, ang.value
 
 
-def select_ccst(path, mapu, map_reso, map_o, pos, global_goal):
-    """global_planner_ccst.py:487-526.  -> (wp ndarray[3], kept cells int32[m, 2])."""
+def select_ccst(path, mapu, map_reso, map_o, pos, global_goal, end_occu=0, return_goal=False):
+    """global_planner_ccst.py:487-544.  -> (wp ndarray[3], kept cells int32[m, 2]) [+ global_goal ndarray[3] after the block
+    when return_goal]."""
     L = _lib.load()
     c = _cells(path)
     occ = as_occ(mapu)
     o, p, g = _vec(map_o, 2), _vec(pos, 3), _vec(global_goal, 3)
     wp = np.zeros(3)
+    gout = np.zeros(3)
     kept = np.zeros((c.shape[0], 2), dtype=np.int32)
     nk = C.c_int32(0)
     rc = L.fxjps_waypoint_ccst(_lib.ptr(c, C.c_int32), c.shape[0], _lib.ptr(occ, C.c_uint8), occ.shape[0], occ.shape[1], float(map_reso),
-                               _lib.ptr(o, C.c_double), _lib.ptr(p, C.c_double), _lib.ptr(g, C.c_double), _lib.ptr(wp, C.c_double),
-                               _lib.ptr(kept, C.c_int32), C.byref(nk))
+                               _lib.ptr(o, C.c_double), _lib.ptr(p, C.c_double), _lib.ptr(g, C.c_double), int(end_occu),
+                               _lib.ptr(wp, C.c_double), _lib.ptr(gout, C.c_double), _lib.ptr(kept, C.c_int32), C.byref(nk))
     if rc != 0:
         raise _lib.FxjpsError(rc, "fxjps_waypoint_ccst: bad argument")
+    if return_goal:
+        return wp, kept[:nk.value].copy(), gout
     return wp, kept[:nk.value].copy()

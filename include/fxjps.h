@@ -53,7 +53,10 @@ typedef struct fxjps fxjps_t;
 #define FXJPS_Q_BAD_START (-2)     /* start outside the grid: the reference raises IndexError */
 #define FXJPS_Q_CAPACITY (-3)      /* search state outgrew device scratch even after the large-scratch retry */
 
-/* backend ids for fxjps_create: only the HIP backend exists. */
+/* backend ids for fxjps_create.  Only the HIP backend exists.  SURVEY.md 8(b) sketched "0 = CPU, 1 = HIP";
+ * id 0 is deliberately NOT implemented and fxjps_create(0, ...) returns FXJPS_E_ARG: a CPU backend inside the product
+ * would be a silent fallback for the very path this library exists to run on the GPU (the only CPU implementation
+ * in the repository is the test oracle under oracle/, which the library never links or loads). */
 #define FXJPS_BACKEND_HIP 1
 
 int fxjps_version(void);
@@ -86,19 +89,43 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H);
  * zero-pad `raw` (W0 x H0, non-zero = occupied) so that start and goal fit, dilate, make the result the
  * resident grid, shift start_xy / goal_xy (in: cell indices relative to `raw`, may be negative; out: indices
  * in the prepared grid) and move a goal that fell on an obstacle to the nearest free cell of its row, else of
- * its column.  out_map_d receives the low-side padding (dx, dy). */
+ * its column.  out_map_d receives the low-side padding (dx, dy).  out_end_occu (may be NULL) receives the
+ * reference's `end_occu` flag: variant 0 -- the shifted goal was on an obstacle (global_planner_st.py:268-275);
+ * variant 1 -- any occupied cell in mapu[gx-ifa:gx+ifa, gy-ifa:gy+ifa] around the (moved) goal
+ * (global_planner_ccst.py:461-464).  It is the `end_occu` argument of fxjps_waypoint_st / _ccst. */
 int fxjps_prepare_grid(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t H0, int32_t ifa, int32_t variant,
-                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d);
+                       int32_t* start_xy, int32_t* goal_xy, int32_t* out_W, int32_t* out_H, int32_t* out_map_d,
+                       int32_t* out_end_occu);
 
 /* Same, straight from a nav_msgs/OccupancyGrid: `data` is the message's int8 data[] (row-major [y][x],
  * width = x extent, height = y extent).  Fuses map_callback (global_planner_st.py:15-20,
  * global_planner_ccst.py:17-23: reshape(h, w).T, 100 -> 1, -1 -> 0) into the preparation kernel. */
 int fxjps_prepare_occupancy_msg(fxjps_t* h, const int8_t* data, int32_t width, int32_t height, int32_t ifa,
                                 int32_t variant, int32_t* start_xy, int32_t* goal_xy, int32_t* out_W,
-                                int32_t* out_H, int32_t* out_map_d);
+                                int32_t* out_H, int32_t* out_map_d, int32_t* out_end_occu);
 
 /* Copy the resident grid back (out may be NULL to query the size only). */
 int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H);
+
+/* ---- Wire / on-disk adapters; device-side byte transposes of the resident grid.
+ *
+ * fxjps_publish_map: the inverse of map_callback, what publish_map (scripts/global_planner_st.py:102-115) puts into
+ * the nav_msgs/OccupancyGrid it publishes: info.width = W (len(data)), info.height = H (len(data[0])),
+ * data[y*W + x] = 100 where the grid is occupied, else 0 (`data.T.reshape(...)`).  out_data holds W*H int8 (NULL:
+ * sizes only).
+ *
+ * fxjps_set_grid_image: the prior-map loader convention of scripts/global_planner_st.py:176-182 on the decoded 8-bit
+ * grey image (`img.convert('L')`, rows x cols, row-major): pixel > 200 is free, anything else occupied, and
+ * map_pre = img[::-1].T, i.e. W = cols, H = rows, grid[x][y] = pixel[rows-1-y][x].  The result becomes the resident
+ * grid (like fxjps_set_grid).
+ *
+ * fxjps_snapshot_image: the snapshot convention of scripts/global_planner_st.py:365-374 (`mapsave.T[::-1]`): an
+ * H-row x W-column image, pixel[r][x] = 255 where grid[x][H-1-r] is free, else 0; channels = 1 ('L') or 3 (the
+ * `.convert('RGB')` replication).  out holds H*W*channels bytes (NULL: sizes only).  set_grid_image(snapshot_image)
+ * reproduces the grid. */
+int fxjps_publish_map(fxjps_t* h, int8_t* out_data, int32_t* out_width, int32_t* out_height);
+int fxjps_set_grid_image(fxjps_t* h, const uint8_t* gray, int32_t rows, int32_t cols);
+int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* out_rows, int32_t* out_cols);
 
 /* Streaming replan: set n cells (xy pairs) to val[i] (0 free / non-zero
  * obstacle) on the resident grid and rebuild the derived maps. */
@@ -165,15 +192,18 @@ int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
  * the reference keeps it when the loop does not pick a new one.  out_wp has out_dim (2 or 3) valid components,
  * out_goal is global_goal after the block (it becomes the vehicle position when end_occu == 1), out_ang_wp ang_wp.
  *
- * fxjps_waypoint_ccst: scripts/global_planner_ccst.py:487-526 with map_line_col (:258-283): points closer than
+ * fxjps_waypoint_ccst: scripts/global_planner_ccst.py:487-544 with map_line_col (:258-283): points closer than
  * 1.5 to the vehicle are dropped, then every point whose neighbours see each other on the grid (occ, uint8 [W][H],
  * obstacle iff == 1: the matrix the search ran on); the waypoint is the 1.4 / 0.6 blend of the second and third
- * remaining points, or the goal.  kept_cells (2 * n int32, optional) / n_kept receive the remaining cells. */
+ * remaining points, or the goal; with end_occu == 1 (:541-544) the vehicle position becomes both waypoint and goal.
+ * out_goal (3 doubles, optional) is global_goal after the block.  kept_cells (2 * n int32, optional) / n_kept
+ * receive the remaining cells. */
 int fxjps_waypoint_st(const int32_t* cells, int32_t n, const int32_t* map_start, double reso, const double* origin, const double* pos,
                       const double* goal, int32_t end_occu, double dis_wp_tre, double ang_wp_tre, const double* prev_wp,
                       int32_t prev_dim, double* out_wp, int32_t* out_dim, double* out_goal, double* out_ang_wp);
 int fxjps_waypoint_ccst(const int32_t* cells, int32_t n, const uint8_t* occ, int32_t W, int32_t H, double reso, const double* origin,
-                        const double* pos, const double* goal, double* out_wp, int32_t* kept_cells, int32_t* n_kept);
+                        const double* pos, const double* goal, int32_t end_occu, double* out_wp, double* out_goal,
+                        int32_t* kept_cells, int32_t* n_kept);
 
 #ifdef __cplusplus
 }

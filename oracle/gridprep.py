@@ -2,7 +2,7 @@
 
 What the two planner nodes do to the occupancy grid right before jps1.method:
     scripts/global_planner_st.py:230-275    (variant 0, "st":   3x3 dilation offsets {-ifa, 0, ifa}, shift map_d - 1)
-    scripts/global_planner_ccst.py:415-458  (variant 1, "ccst": full (2*ifa+1)^2 dilation,          shift map_d)
+    scripts/global_planner_ccst.py:415-464  (variant 1, "ccst": full (2*ifa+1)^2 dilation,          shift map_d)
 Pinned by tests/golden/gridprep.json, whose expected outputs were produced by executing those very line
 ranges of the reference files (tests/golden/make_golden_gridprep.py).
 """
@@ -11,7 +11,12 @@ import numpy as np
 
 def prepare(raw, start, goal, ifa, variant):
     """raw: 2-D array, > 0 = occupied.  start/goal: cell indices before padding (may be negative).
-    -> (grid uint8 [W1][H1] of 0/1, start' (x, y), goal' (x, y), map_d (dx, dy))"""
+    -> (grid uint8 [W1][H1] of 0/1, start' (x, y), goal' (x, y), map_d (dx, dy)); prepare_full adds end_occu."""
+    return prepare_full(raw, start, goal, ifa, variant)[:4]
+
+
+def prepare_full(raw, start, goal, ifa, variant):
+    """-> (grid, start', goal', map_d, end_occu)   (end_occu: st:268-275 / ccst:461-464)"""
     raw = np.asarray(raw)
     W0, H0 = raw.shape
     sx, sy = int(start[0]), int(start[1])
@@ -39,11 +44,16 @@ def prepare(raw, start, goal, ifa, variant):
     sx, sy = sx + dx - sh, sy + dy - sh
     gx, gy = gx + dx - sh, gy + dy - sh
     # st:268-272 / ccst:454-458: a goal on an obstacle moves to the nearest free cell of its row, else column
+    end_occu = 0
     if grid[gx, gy] == 1:
+        if variant == 0:
+            end_occu = 1  # st:273
         free = np.where(grid[gx, :] == 0)[0]
         if len(free):
             gy = int(free[np.argmin(np.abs(free - gy))])
         else:
             free = np.where(grid[:, gy] == 0)[0]
             gx = int(free[np.argmin(np.abs(free - gx))])  # raises on an all-occupied column, like the reference
-    return (grid == 1).astype(np.uint8), (sx, sy), (gx, gy), (dx, dy)
+    if variant == 1:  # ccst:461-464 (numpy slice rules apply to negative bounds)
+        end_occu = int((grid[gx - ifa:gx + ifa, gy - ifa:gy + ifa] == 1).any())
+    return (grid == 1).astype(np.uint8), (sx, sy), (gx, gy), (dx, dy), end_occu

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden vectors for the callers' grid preparation, produced by EXECUTING the reference's
-own lines: scripts/global_planner_st.py:230-272 and scripts/global_planner_ccst.py:415-458 are read from
+own lines: scripts/global_planner_st.py:230-275 and scripts/global_planner_ccst.py:415-464 (through `end_occu`) are read from
 /root/reference at generation time, dedented and exec'ed on prepared inputs.  Only inputs and outputs are stored.
 
     python tests/golden/make_golden_gridprep.py
@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/scripts"
-RANGES = {0: ("global_planner_st.py", 230, 272, 1), 1: ("global_planner_ccst.py", 415, 458, 2)}
+RANGES = {0: ("global_planner_st.py", 230, 275, 1), 1: ("global_planner_ccst.py", 415, 464, 2)}
 
 
 def ref_block(variant):
@@ -31,7 +31,7 @@ def run_ref(variant, raw, start, goal, ifa):
     assert set(np.unique(g)) <= {0.0, 1.0}
     return {"grid_shape": list(g.shape), "grid_bits": np.packbits((g == 1).astype(np.uint8)).tobytes().hex(),
             "start_out": [int(v) for v in ns["map_start"]], "goal_out": [int(v) for v in ns["map_goal"]],
-            "map_d": [int(v) for v in ns["map_d"]]}
+            "map_d": [int(v) for v in ns["map_d"]], "end_occu": int(ns["end_occu"])}
 
 
 def run_ref_callback(msg, width, height):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end golden vectors of one planner tick (N1 -> hot path -> N2), produced by EXECUTING the
-reference: the grid-preparation lines (global_planner_st.py:230-272 / global_planner_ccst.py:415-458), the real
-scripts/jps1.py, and the waypoint lines (global_planner_st.py:292-327 / global_planner_ccst.py:487-526 with
+reference: the grid-preparation lines (global_planner_st.py:230-275 / global_planner_ccst.py:415-464, through end_occu), the real
+scripts/jps1.py, and the waypoint lines (global_planner_st.py:292-327 / global_planner_ccst.py:487-544 with
 map_line_col) are read from /root/reference at generation time and run on prepared inputs.  Only inputs and outputs
 are stored.
 
@@ -42,12 +42,12 @@ def tick(P, variant, raw, start, goal, ifa, reso, origin, pos, goal3, prev_wp):
         ns["path1"] = path1
         rec = {"map_start": [int(v) for v in ms], "map_goal": [int(v) for v in mg], "grid_shape": list(ns["mapu"].shape)}
         if isinstance(path1[0], int):  # (0, t): no path
-            rec.update(path=None, wp=[float(v) for v in goal3])
+            rec.update(path=None, wp=[float(v) for v in goal3], end_occu=int(ns["end_occu"]))
             return rec
         if variant == 0:
             block = textwrap.dedent(ref_lines("global_planner_st.py", 292, 327))                 # N2
         else:
-            block = textwrap.dedent(ref_lines("global_planner_ccst.py", 487, 526))
+            block = textwrap.dedent(ref_lines("global_planner_ccst.py", 487, 544))
         exec(compile(block, "N2", "exec"), ns)
     rec.update(path=[[int(x), int(y)] for x, y in path1[0]], wp=[float(v) for v in ns["wp"]],
                goal_out=[float(v) for v in ns["global_goal"]], end_occu=int(ns["end_occu"]))
@@ -68,6 +68,10 @@ def main():
         lo = -4 if tries % 4 == 0 else 0
         start = [int(rng.integers(lo, W0 + 4)), int(rng.integers(lo, H0 + 4))]
         goal = [int(rng.integers(lo, W0 + 4)), int(rng.integers(lo, H0 + 4))]
+        occ_cells = np.argwhere(raw == 1)
+        if tries % 3 == 1 and len(occ_cells):  # a goal on (or next to) an obstacle: end_occu = 1 ticks
+            c = occ_cells[int(rng.integers(0, len(occ_cells)))]
+            goal = [int(c[0]) + int(rng.integers(0, 2)), int(c[1]) + int(rng.integers(0, 2))]
         reso = float(rng.choice([0.1, 0.2, 0.5]))
         origin = [float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))]
         pos = [float(start[0] * reso + origin[0] + rng.normal(0, 0.2)), float(start[1] * reso + origin[1] + rng.normal(0, 0.2)), float(rng.choice([0.5, 1.0]))]
@@ -85,7 +89,7 @@ def main():
     p = os.path.join(HERE, "tick.json")
     with open(p, "w") as f:
         json.dump(out, f, separators=(",", ":"))
-    print("wrote", p, len(out), "ticks;", sum(r["path"] is None for r in out), "without a path;",
+    print("wrote", p, len(out), "ticks;", sum(r["end_occu"] for r in out), "with end_occu = 1;", sum(r["path"] is None for r in out), "without a path;",
           sum(r["path"] is not None and r["wp"][:2] != r["goal3"][:2] for r in out), "with an intermediate waypoint")
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden vectors for the waypoint post-processing that follows a plan, produced by EXECUTING
-the reference's own lines: scripts/global_planner_st.py:292-327 and scripts/global_planner_ccst.py:487-526 (with
+the reference's own lines: scripts/global_planner_st.py:292-327 and scripts/global_planner_ccst.py:487-544 (with
 `map_line_col`, ccst:258-283) are read from /root/reference at generation time, dedented and exec'ed on prepared
 inputs.  Only inputs and outputs are stored.
 
@@ -46,14 +46,15 @@ def run_st(path, map_start, reso, origin, pos, goal, end_occu, prev_wp):
     return {"wp": [float(v) for v in ns["wp"]], "goal_out": [float(v) for v in ns["global_goal"]], "ang_wp": float(ns["ang_wp"])}
 
 
-def run_ccst(P, path, mapu, reso, origin, pos, goal):
+def run_ccst(P, path, mapu, reso, origin, pos, goal, end_occu=0):
     ns = {"np": np, "math": math, "path1": (list(map(tuple, path)), 0.0), "map_reso": reso, "map_o": np.array(origin),
-          "global_goal": np.array(goal), "px": pos[0], "py": pos[1], "pz": pos[2], "mapu": mapu, "planner": P}
-    block = textwrap.dedent(ref_lines("global_planner_ccst.py", 487, 526))
+          "global_goal": np.array(goal), "px": pos[0], "py": pos[1], "pz": pos[2], "mapu": mapu, "planner": P, "end_occu": end_occu}
+    block = textwrap.dedent(ref_lines("global_planner_ccst.py", 487, 544))
     with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        exec(compile(block, "ccst:487-526", "exec"), ns)
-    return {"wp": [float(v) for v in ns["wp"]], "kept": [[int(c[0]), int(c[1])] for c in ns["path2_c"]]}
+        exec(compile(block, "ccst:487-544", "exec"), ns)
+    return {"wp": [float(v) for v in ns["wp"]], "kept": [[int(c[0]), int(c[1])] for c in ns["path2_c"]],
+            "goal_out": [float(v) for v in ns["global_goal"]]}
 
 
 def main():
@@ -91,8 +92,9 @@ def main():
             rec.update({"variant": 0, "map_start": map_start, "end_occu": end_occu, "prev_wp": prev})
             rec["out"] = run_st(path, map_start, reso, origin, pos, goal, end_occu, prev)
         else:
-            rec.update({"variant": 1})
-            rec["out"] = run_ccst(P, path, occ.astype(np.float64), reso, origin, pos, goal)
+            end_occu = int(rng.random() < 0.15)
+            rec.update({"variant": 1, "end_occu": end_occu})
+            rec["out"] = run_ccst(P, path, occ.astype(np.float64), reso, origin, pos, goal, end_occu)
         out.append(rec)
     p = os.path.join(HERE, "waypoints.json")
     with open(p, "w") as f:

@@ -1,4 +1,4 @@
-"""Grid preparation: global_planner_st.py:230-272 / global_planner_ccst.py:415-458.
+"""Grid preparation: global_planner_st.py:230-275 / global_planner_ccst.py:415-464 (through end_occu).
 Golden vectors come from executing those reference lines (tests/golden/make_golden_gridprep.py)."""
 import numpy as np
 import pytest
@@ -16,14 +16,17 @@ def test_oracle_restatement_matches_reference_lines():
     recs = load_golden("gridprep.json")
     assert len(recs) >= 200 and {r["variant"] for r in recs} == {0, 1}
     moved = 0
+    eo = [0, 0]
     for r in recs:
         raw = unpack(r["raw_bits"], r["raw_shape"])
-        g, s, go, d = gridprep.prepare(raw, r["start"], r["goal"], r["ifa"], r["variant"])
+        g, s, go, d, e = gridprep.prepare_full(raw, r["start"], r["goal"], r["ifa"], r["variant"])
         assert list(g.shape) == r["grid_shape"] and np.array_equal(g, unpack(r["grid_bits"], r["grid_shape"]))
-        assert list(s) == r["start_out"] and list(go) == r["goal_out"] and list(d) == r["map_d"]
+        assert list(s) == r["start_out"] and list(go) == r["goal_out"] and list(d) == r["map_d"] and e == r["end_occu"]
         sh = 1 if r["variant"] == 0 else 0
         moved += list(go) != [r["goal"][0] + d[0] - sh, r["goal"][1] + d[1] - sh]
+        eo[r["variant"]] += e
     assert moved > 20  # the goal-on-obstacle relocation is exercised
+    assert eo[0] > 10 and eo[1] > 10  # ... and so is end_occu = 1, for both nodes
 
 
 @pytest.mark.gpu
@@ -32,8 +35,9 @@ def test_device_grid_preparation_matches_goldens():
     with fx.Planner([0]) as p:
         for r in load_golden("gridprep.json"):
             raw = unpack(r["raw_bits"], r["raw_shape"])
-            s, g, d, shape = p.prepare_grid(raw, r["start"], r["goal"], r["ifa"], r["variant"])
+            s, g, d, shape, eo = p.prepare_grid(raw, r["start"], r["goal"], r["ifa"], r["variant"])
             assert list(shape) == r["grid_shape"] and list(s) == r["start_out"] and list(g) == r["goal_out"] and list(d) == r["map_d"]
+            assert eo == r["end_occu"]
             assert np.array_equal(p.get_grid(), unpack(r["grid_bits"], r["grid_shape"]))
 
 
@@ -52,11 +56,11 @@ def test_prepare_then_plan_equals_host_prepared_grid(oracle):
             goal = (int(rng.integers(0, W0 + 3)), int(rng.integers(0, H0 + 3)))
             variant, ifa = it & 1, 1 + (it & 1)
             try:
-                eg, es, ego, ed = gridprep.prepare(raw, start, goal, ifa, variant)
+                eg, es, ego, ed, eeo = gridprep.prepare_full(raw, start, goal, ifa, variant)
             except (IndexError, ValueError):
                 continue
-            s, g, d, shape = p.prepare_grid(raw, start, goal, ifa, variant)
-            assert (s, g, d) == (es, ego, ed) and shape == eg.shape
+            s, g, d, shape, eo = p.prepare_grid(raw, start, goal, ifa, variant)
+            assert (s, g, d, eo) == (es, ego, ed, eeo) and shape == eg.shape
             if not (0 <= s[0] < shape[0] and 0 <= s[1] < shape[1]):
                 continue
             off, cells, cost, st = p.plan_batch([s], [g], 2)
@@ -90,9 +94,9 @@ def test_prepare_from_occupancy_message():
             m = np.array(r["map"], dtype=np.int64).reshape(w, h)  # what map_callback stores
             start, goal, ifa, variant = (0, 0), (w - 1, h - 1), 1 + (k & 1), k & 1
             try:
-                eg, es, ego, ed = gridprep.prepare(m, start, goal, ifa, variant)
+                eg, es, ego, ed, eeo = gridprep.prepare_full(m, start, goal, ifa, variant)
             except (IndexError, ValueError):
                 continue
-            s, g, d, shape = p.prepare_occupancy_msg(np.array(r["data"], dtype=np.int8), w, h, start, goal, ifa, variant)
-            assert (s, g, d) == (es, ego, ed) and shape == eg.shape
+            s, g, d, shape, eo = p.prepare_occupancy_msg(np.array(r["data"], dtype=np.int8), w, h, start, goal, ifa, variant)
+            assert (s, g, d, eo) == (es, ego, ed, eeo) and shape == eg.shape
             assert np.array_equal(p.get_grid(), eg)

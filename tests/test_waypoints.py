@@ -1,5 +1,5 @@
 """Waypoint post-processing against vectors produced by executing the reference's own lines
-(tests/golden/make_golden_waypoints.py: global_planner_st.py:292-327, global_planner_ccst.py:487-526 + :258-283).
+(tests/golden/make_golden_waypoints.py: global_planner_st.py:292-327, global_planner_ccst.py:487-544 + :258-283).
 Host functions of the C ABI: no GPU needed."""
 import json
 import os
@@ -39,17 +39,20 @@ def test_st_rule_matches_reference_lines():
 
 
 def test_ccst_pruning_matches_reference_lines():
-    n = pruned = 0
+    n = pruned = held = 0
     for rec in cases():
         if rec["variant"] != 1:
             continue
-        wp, kept = waypoints.select_ccst(rec["path"], grid_of(rec), rec["reso"], rec["origin"], rec["pos"], rec["goal"])
+        wp, kept, goal = waypoints.select_ccst(rec["path"], grid_of(rec), rec["reso"], rec["origin"], rec["pos"], rec["goal"],
+                                               rec["end_occu"], return_goal=True)
         exp = rec["out"]
         assert kept.tolist() == exp["kept"], (n, kept.tolist(), exp["kept"])
         assert wp.tolist() == exp["wp"], (n, wp, exp["wp"])
+        assert goal.tolist() == exp["goal_out"]
         pruned += len(exp["kept"]) < len(rec["path"])
+        held += rec["end_occu"]
         n += 1
-    assert n == 150 and pruned > 100
+    assert n == 150 and pruned > 100 and held > 10  # end_occu = 1: the vehicle holds position (ccst:541-544)
 
 
 def test_edge_cases():
