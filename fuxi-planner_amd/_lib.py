@@ -21,7 +21,8 @@ SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy
 
 class Timing(C.Structure):
     _fields_ = [("search_kernel_ms", C.c_double), ("total_ms", C.c_double), ("search_launches", C.c_int64),
-                ("retried", C.c_int64), ("pops", C.c_int64), ("pushes", C.c_int64)]
+                ("retried", C.c_int64), ("pops", C.c_int64), ("pushes", C.c_int64), ("far_refills", C.c_int64),
+                ("slow_pops", C.c_int64), ("table_wipes", C.c_int64)]
 
 
 class FxjpsError(RuntimeError):
@@ -31,6 +32,21 @@ class FxjpsError(RuntimeError):
 
 
 _lib = None
+
+
+def bind_host(L):
+    """Prototypes of the host-only entry points (csrc/fxjps_waypoints.cpp); also used on the sanitizer build of that
+    translation unit by the CPU test-suite."""
+    p_i32 = C.POINTER(C.c_int32)
+    p_u8 = C.POINTER(C.c_uint8)
+    p_f64 = C.POINTER(C.c_double)
+    L.fxjps_waypoint_st.restype = C.c_int
+    L.fxjps_waypoint_st.argtypes = [p_i32, C.c_int32, p_i32, C.c_double, p_f64, p_f64, p_f64, C.c_int32, C.c_double, C.c_double,
+                                    p_f64, C.c_int32, p_f64, p_i32, p_f64, p_f64]
+    L.fxjps_waypoint_ccst.restype = C.c_int
+    L.fxjps_waypoint_ccst.argtypes = [p_i32, C.c_int32, p_u8, C.c_int32, C.c_int32, C.c_double, p_f64, p_f64, p_f64, C.c_int32, p_f64, p_f64,
+                                      p_i32, p_i32]
+    return L
 
 
 def load():
@@ -89,12 +105,7 @@ def load():
     L.fxjps_selftest_wavemin.argtypes = [vp, C.c_int32, C.c_uint64, p_i64]
     L.fxjps_debug_read_nbmask.restype = C.c_int
     L.fxjps_debug_read_nbmask.argtypes = [vp, p_u8]
-    L.fxjps_waypoint_st.restype = C.c_int
-    L.fxjps_waypoint_st.argtypes = [p_i32, C.c_int32, p_i32, C.c_double, p_f64, p_f64, p_f64, C.c_int32, C.c_double, C.c_double,
-                                    p_f64, C.c_int32, p_f64, p_i32, p_f64, p_f64]
-    L.fxjps_waypoint_ccst.restype = C.c_int
-    L.fxjps_waypoint_ccst.argtypes = [p_i32, C.c_int32, p_u8, C.c_int32, C.c_int32, C.c_double, p_f64, p_f64, p_f64, C.c_int32, p_f64, p_f64,
-                                      p_i32, p_i32]
+    bind_host(L)
     _lib = L
     return L
 

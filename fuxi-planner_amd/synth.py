@@ -64,3 +64,37 @@ def synth_queries(occ, qseed, n, first=0):
             start = xy
         out.append(xy.astype(np.int32))
     return out[0], out[1]
+
+
+def synth_toggles(occ, keep, frame, frac=0.05, seed=5):
+    """Frame update of the streaming-replan configuration: exactly k = floor(frac*W*H)
+    currently occupied cells become free and k currently free cells become occupied (10 % of the cells toggled at
+    frac = 0.05, the density stays put), chosen by the same counter-based PRNG keyed by the frame index; cells of
+    `keep` (bool [W][H]: the query end points) are never touched.
+
+        fkey = splitmix64(splitmix64(seed ^ 0x4652414D45) ^ frame);   r(cell) = splitmix64(fkey ^ (x*H + y))
+        the k occupied cells with the smallest r turn free, the k free non-kept cells with the smallest r turn occupied
+
+    -> (xy int32[2k, 2], val uint8[2k]) in ascending cell order per class (free-ing first); `occ` is not modified."""
+    occ = np.asarray(occ)
+    W, H = occ.shape
+    k = int(frac * W * H)
+    fkey = splitmix64(np.array([splitmix64(np.array([np.uint64(seed) ^ np.uint64(0x4652414D45)], dtype=np.uint64))[0]
+                                ^ np.uint64(frame)], dtype=np.uint64))[0]
+    r = splitmix64(fkey ^ np.arange(W * H, dtype=np.uint64))
+    flat = occ.ravel() != 0
+    out_idx, out_val = [], []
+    for cls, v in ((flat, 0), (~flat & ~np.asarray(keep, dtype=bool).ravel(), 1)):
+        cand = np.flatnonzero(cls)
+        kk = min(k, len(cand))
+        sel = cand[np.argpartition(r[cand], kk - 1)[:kk]] if kk > 0 else cand[:0]
+        out_idx.append(np.sort(sel))
+        out_val.append(np.full(kk, v, dtype=np.uint8))
+    idx = np.concatenate(out_idx)
+    xy = np.stack([idx // H, idx % H], 1).astype(np.int32)
+    return xy, np.concatenate(out_val)
+
+
+def apply_toggles(occ, xy, val):
+    occ[xy[:, 0], xy[:, 1]] = val
+    return occ

@@ -19,6 +19,13 @@ from . import _lib
 from .planner import as_occ
 
 
+_HOST_LIB = None  # test hook: a library with the host-only entry points (e.g. the sanitizer build); None = libfxjps.so
+
+
+def _L():
+    return _HOST_LIB if _HOST_LIB is not None else _lib.load()
+
+
 def _cells(path):
     c = np.ascontiguousarray(np.asarray(path, dtype=np.int32).reshape(-1, 2))
     if c.shape[0] < 1:
@@ -36,7 +43,7 @@ def _vec(v, n):
 def select_st(path, map_start, map_reso, map_o, pos, global_goal, end_occu=0, prev_wp=None, dis_wp_tre=2.0,
               ang_wp_tre=math.pi / 4):
     """global_planner_st.py:292-327.  -> (wp ndarray of 2 or 3 components, global_goal ndarray[3], ang_wp)."""
-    L = _lib.load()
+    L = _L()
     c = _cells(path)
     ms = np.ascontiguousarray(np.asarray(map_start, dtype=np.int32).ravel())
     o, p, g = _vec(map_o, 2), _vec(pos, 3), _vec(global_goal, 3)
@@ -57,7 +64,7 @@ def select_st(path, map_start, map_reso, map_o, pos, global_goal, end_occu=0, pr
 def select_ccst(path, mapu, map_reso, map_o, pos, global_goal, end_occu=0, return_goal=False):
     """global_planner_ccst.py:487-544.  -> (wp ndarray[3], kept cells int32[m, 2]) [+ global_goal ndarray[3] after the block
     when return_goal]."""
-    L = _lib.load()
+    L = _L()
     c = _cells(path)
     occ = as_occ(mapu)
     o, p, g = _vec(map_o, 2), _vec(pos, 3), _vec(global_goal, 3)

@@ -167,6 +167,9 @@ typedef struct fxjps_timing {
     int64_t retried;         /* queries re-run with large scratch */
     int64_t pops;            /* open-list pops executed by the last batch (all devices) */
     int64_t pushes;
+    int64_t far_refills;     /* open-list refills from the global-memory tier */
+    int64_t slow_pops;       /* pops taken straight from the global-memory tier (> 256 entries tied at the minimum key) */
+    int64_t table_wipes;     /* visited-table wipes after a wavefront's generation counter wrapped (every 63 searches) */
 } fxjps_timing_t;
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
 

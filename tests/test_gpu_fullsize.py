@@ -1,0 +1,298 @@
+"""GPU suite (-m gpu), BASELINE configurations at their stated sizes and the cold paths of the HIP planner:
+config-4 shard (125 000 queries in one batch), config 3 (4096^2: 2 000 queries against the oracle, the full 100 000 run
+through invariants), config 5 (streaming frames with the SURVEY 8d toggle stream), forced scratch overflow -> large-pool
+retry, generation wrap + table wipe, the > 256-equal-keys far path, adopt-a-device-buffer, and the multi-process path
+around the real planner.  Everything is compared bit for bit (cells, lengths, float64 cost)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import path_invariants
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NTHREADS = min(os.cpu_count() or 8, 128)
+
+
+@pytest.fixture(scope="module")
+def planner():
+    import fuxi_planner_amd as fx
+    p = fx.Planner([0])
+    yield p
+    p.close()
+
+
+def oracle_csr(oracle, occ, s, g, h, max_len, nthreads=NTHREADS):
+    """The oracle's answer in the planner's CSR layout."""
+    oc, ol, ocost, _ = oracle.plan_batch(occ, s, g, h, literal=False, max_len=max_len, nthreads=nthreads)
+    keep = np.arange(max_len)[None, :] < np.maximum(ol, 0)[:, None]
+    off = np.zeros(len(ol) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.maximum(ol, 0))
+    return off, oc[keep], ocost, ol
+
+
+def assert_same(a, b):
+    off, cells, cost, st = a
+    off2, cells2, cost2, st2 = b
+    assert np.array_equal(st, st2)
+    assert np.array_equal(off, off2)
+    assert cost.tobytes() == cost2.tobytes()
+    assert np.array_equal(cells, cells2)
+
+
+def with_env(**kv):
+    class _E(object):
+        def __enter__(self):
+            self.old = {k: os.environ.get(k) for k in kv}
+            for k, v in kv.items():
+                os.environ[k] = str(v)
+
+        def __exit__(self, *a):
+            for k, v in self.old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _E()
+
+
+# ------------------------------------------------------------------ arithmetic at the largest accepted grid
+def test_device_sqrt_is_correctly_rounded_up_to_8190(planner):
+    """fxjps_set_grid accepts up to 8190 cells a side: every sqrt argument is <= 2 * 8189^2 (jps1.py:12,246)."""
+    hi = 2 * 8189 * 8189 + 1
+    step = 1 << 24
+    for n0 in range(2 * 4095 * 4095, hi, step):  # (test_gpu_parity covers [0, 2*4095^2])
+        n1 = min(hi, n0 + step)
+        got = planner.selftest_sqrt(n0, n1)
+        assert np.array_equal(got, np.sqrt(np.arange(n0, n1, dtype=np.float64)))
+
+
+# ------------------------------------------------------------------ config 4: one GPU's shard of the 1 M queries
+def test_config4_shard_125k(planner, oracle):
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(1024, 1024, 1, 0.20)
+    planner.set_grid_occ(occ)
+    nq = 125000
+    s, g = synth.synth_queries(occ, 1, nq)
+    res = planner.plan_batch(s, g, 2, 1024)
+    tm = planner.timing()
+    assert (res[3] >= 0).all() and tm["retried"] == 0
+    assert_same(res, oracle_csr(oracle, occ, s, g, 2, 1024))          # every path of the shard against the oracle
+    # the first 10 000 queries of the stream are config 2: same bytes as a 10 000-query batch
+    r2 = planner.plan_batch(s[:10000], g[:10000], 2, 1024)
+    off, cells, cost, st = res
+    assert np.array_equal(r2[3], st[:10000]) and r2[2].tobytes() == cost[:10000].tobytes()
+    assert np.array_equal(r2[1], cells[:off[10000]])
+    # two halves concatenated are byte-identical to the one batch (what the rank merge relies on)
+    from fuxi_planner_amd.distributed import merge_csr
+    halves = [planner.plan_batch(s[a:b], g[a:b], 2, 1024) for a, b in ((0, nq // 2), (nq // 2, nq))]
+    assert_same(merge_csr(halves), res)
+
+
+# ------------------------------------------------------------------ config 3: 4096 x 4096, 100 000 queries
+def test_config3_full(planner, oracle):
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(4096, 4096, 2, 0.20)
+    planner.set_grid_occ(occ)
+    nq = 100000
+    s, g = synth.synth_queries(occ, 2, nq)
+    off, cells, cost, st = planner.plan_batch(s, g, 2, 4096)
+    assert (st >= 0).all(), np.unique(st[st < 0], return_counts=True)  # no capacity / length / watchdog code
+    assert (st > 0).sum() > 0.98 * nq
+    n_or = 2000  # the oracle needs ~0.5 M pops per query here: a 2 000-query prefix bit for bit ...
+    o_off, o_cells, o_cost, o_len = oracle_csr(oracle, occ, s[:n_or], g[:n_or], 2, 4096, nthreads=min(NTHREADS, 64))
+    assert np.array_equal(st[:n_or], o_len) and cost[:n_or].tobytes() == o_cost.tobytes()
+    assert np.array_equal(off[:n_or + 1], o_off) and np.array_equal(cells[:off[n_or]], o_cells)
+    sel = np.arange(n_or, nq, 197)  # ... and size-independent invariants on a sample of the rest
+    o2 = np.zeros(len(sel) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum(np.maximum(st[sel], 0))
+    c2 = np.concatenate([cells[off[q]:off[q + 1]] for q in sel])
+    path_invariants(occ, s[sel], g[sel], o2, c2, cost[sel], st[sel])
+    # unreachable goals are exactly the cross-component ones (4-connected components)
+    from scipy import ndimage
+    lab, _ = ndimage.label(occ == 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    same = lab[s[:, 0], s[:, 1]] == lab[g[:, 0], g[:, 1]]
+    assert np.array_equal(st > 0, same)
+
+
+# ------------------------------------------------------------------ config 5: streaming replan
+def test_config5_frames(planner, oracle):
+    """1024^2, 1 000 persistent (start, goal) pairs, each frame toggles floor(0.05*W*H) occupied -> free and as many
+    free -> occupied cells (SURVEY 8d PRNG, end points never touched); every path of every frame against the oracle."""
+    from fuxi_planner_amd import synth
+    W = H = 1024
+    occ = synth.synth_grid(W, H, 1, 0.20)
+    s, g = synth.synth_queries(occ, 5, 1000)
+    keep = np.zeros((W, H), dtype=bool)
+    keep[s[:, 0], s[:, 1]] = True
+    keep[g[:, 0], g[:, 1]] = True
+    planner.set_grid_occ(occ)
+    prev = None
+    for frame in range(6):
+        xy, val = synth.synth_toggles(occ, keep, frame)
+        assert len(val) == 2 * int(0.05 * W * H) and (val == 0).sum() == (val == 1).sum()
+        assert (occ[xy[:, 0], xy[:, 1]] != val).all() and not keep[xy[:, 0], xy[:, 1]].any()
+        planner.update_cells(xy, val)
+        synth.apply_toggles(occ, xy, val)
+        assert int(occ.sum()) == int(synth.synth_grid(W, H, 1, 0.20).sum())  # the density stays put
+        res = planner.plan_batch(s, g, 2, 2048)
+        assert_same(res, oracle_csr(oracle, occ, s, g, 2, 2048))
+        assert prev is None or not np.array_equal(prev, res[2])  # the frames really differ
+        prev = res[2].copy()
+    assert np.array_equal(planner.get_grid(), occ)
+
+
+# ------------------------------------------------------------------ cold paths, forced
+def test_scratch_overflow_retries_on_the_large_pool(planner, oracle):
+    """A visited table of 2^8 entries / a 64-entry far tier: most queries outgrow the first pool (QI_TABLE_FULL,
+    QI_FAR_FULL, walk-back scratch) and are re-run with the large one -- same bytes as the regular configuration."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(320, 288, 21, 0.22)
+    s, g = synth.synth_queries(occ, 21, 600)
+    planner.set_grid_occ(occ)
+    ref = planner.plan_batch(s, g, 2, 512)
+    assert planner.timing()["retried"] == 0
+    assert_same(ref, oracle_csr(oracle, occ, s, g, 2, 512))
+    for env in ({"FXJPS_TABLE_LOG2": 8}, {"FXJPS_FAR_CAP": 64}, {"FXJPS_TABLE_LOG2": 10, "FXJPS_FAR_CAP": 64, "FXJPS_POOL_BUDGET_MB": 64}):
+        with with_env(**env):
+            planner.set_grid_occ(occ)  # new scratch configuration
+            for h in (2, 1):
+                res = planner.plan_batch(s, g, h, 512)
+                print("retry", env, h, planner.timing())
+                assert planner.timing()["retried"] > 0, (env, planner.timing())
+                assert (res[3] >= 0).all()
+                assert_same(res, ref if h == 2 else oracle_csr(oracle, occ, s, g, 1, 512))
+    planner.set_grid_occ(occ)
+    assert_same(planner.plan_batch(s, g, 2, 512), ref)
+
+
+def test_generation_wrap_and_table_wipe(planner, oracle):
+    """8 resident wavefronts and 2 400 queries: 300 searches per wavefront, i.e. four wraps of the 6-bit generation
+    tag with a table wipe each."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(200, 240, 33, 0.20)
+    s, g = synth.synth_queries(occ, 33, 2400)
+    with with_env(FXJPS_WAVES=8):
+        planner.set_grid_occ(occ)
+        res = planner.plan_batch(s, g, 2, 512)
+        assert planner.timing()["table_wipes"] >= 16, planner.timing()
+        res2 = planner.plan_batch(s, g, 2, 512)  # generation counters carry over between batches
+        assert planner.timing()["table_wipes"] >= 16
+    assert_same(res, oracle_csr(oracle, occ, s, g, 2, 512))
+    assert_same(res2, res)
+
+
+def test_equal_key_far_path(planner, oracle):
+    """Open grids with the octile heuristic: thousands of equal f values per level.  The far tier is refilled by
+    (x, y) slices and, with more than 256 entries tied at the minimum key, popped directly."""
+    rng = np.random.default_rng(8)
+    W, H = 900, 1100
+    occ = np.zeros((W, H), dtype=np.uint8)
+    occ[rng.integers(0, W, 400), rng.integers(0, H, 400)] = 1
+    free = np.argwhere(occ == 0)
+    n = 200
+    s = free[rng.integers(0, len(free), n)].astype(np.int32)
+    g = free[rng.integers(0, len(free), n)].astype(np.int32)
+    planner.set_grid_occ(occ)
+    res = planner.plan_batch(s, g, 1, 2048)
+    tm = planner.timing()
+    print("equal-key", tm)
+    assert tm["far_refills"] > 0, tm
+    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 2048))
+    # all-equal keys: an empty grid where every node of a level ties (f constant along the diagonal band)
+    occ2 = np.zeros((700, 700), dtype=np.uint8)
+    s2 = np.tile(np.array([[0, 350]], dtype=np.int32), (8, 1))
+    g2 = np.array([[699, 350 + k] for k in range(8)], dtype=np.int32)
+    planner.set_grid_occ(occ2)
+    res2 = planner.plan_batch(s2, g2, 1, 2048)
+    print("equal-key empty grid", planner.timing())
+    assert_same(res2, oracle_csr(oracle, occ2, s2, g2, 1, 2048))
+
+
+# ------------------------------------------------------------------ device-buffer adoption, multi-process path
+def test_set_grid_device_equals_host_upload(planner):
+    torch = pytest.importorskip("torch")
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(300, 260, 12, 0.20)
+    s, g = synth.synth_queries(occ, 12, 500)
+    planner.set_grid_occ(occ)
+    ref = planner.plan_batch(s, g, 2, 512)
+    planner.set_grid_occ(np.zeros((4, 4), dtype=np.uint8))
+    buf = torch.from_numpy(occ.reshape(-1).copy()).to("cuda:0")  # e.g. the receive buffer of an RCCL broadcast
+    torch.cuda.synchronize()
+    planner.set_grid_device(buf.data_ptr(), 300, 260)
+    del buf
+    assert np.array_equal(planner.get_grid(), occ)
+    assert_same(planner.plan_batch(s, g, 2, 512), ref)
+
+
+_WORKER = r'''
+import os, sys, pickle
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+import fuxi_planner_amd as fx
+from fuxi_planner_amd import synth
+from fuxi_planner_amd.distributed import ShardedPlanner
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank = dist.get_rank()
+planner = fx.Planner([0])                      # the real HIP planner; both ranks share GPU 0 on a 1-GPU box
+sp = ShardedPlanner(planner, device="cpu")     # host-side broadcast (gloo); with nccl the buffer would be on the device
+full = synth.synth_grid(384, 320, 17, 0.20)
+sp.set_grid(full if rank == 0 else None)
+assert np.array_equal(planner.get_grid(), full)
+s, g = synth.synth_queries(full, 17, 1501)
+res = sp.plan(s, g, 2, 512)
+if rank == 0:
+    with open(%(out)r, "wb") as f:
+        pickle.dump(res, f)
+lo, hi = sp.plan_local(s, g, 2, 512)[:2]
+print("RANK", rank, lo, hi, flush=True)
+dist.barrier()
+planner.close()
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_sharded_planner_on_one_gpu(planner, tmp_path):
+    """ShardedPlanner around the REAL planner, two processes (both on GPU 0, gloo rendezvous): the merged CSR is
+    byte-identical to the one-process result."""
+    import pickle
+    from fuxi_planner_amd import synth
+    out = tmp_path / "merged.pkl"
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT, "out": str(out)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "RANK 0 0 750" in outs[0] and "RANK 1 750 1501" in outs[1]
+    with open(out, "rb") as f:
+        merged = pickle.load(f)
+    occ = synth.synth_grid(384, 320, 17, 0.20)
+    s, g = synth.synth_queries(occ, 17, 1501)
+    planner.set_grid_occ(occ)
+    assert_same(merged, planner.plan_batch(s, g, 2, 512))
+
+
+def test_in_library_multi_device_handle(planner):
+    """fxjps_create(n_dev = 2): RCCL broadcast of the grid + contiguous shards inside the library (no torch)."""
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import _lib, synth
+    if _lib.load().fxjps_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    occ = synth.synth_grid(512, 512, 3, 0.20)
+    s, g = synth.synth_queries(occ, 3, 4001)
+    planner.set_grid_occ(occ)
+    ref = planner.plan_batch(s, g, 2, 1024)
+    with fx.Planner([0, 1]) as p2:
+        p2.set_grid_occ(occ)
+        assert_same(p2.plan_batch(s, g, 2, 1024), ref)
+        xy = np.array([[5, 5], [100, 7]], dtype=np.int32)
+        p2.update_cells(xy, np.array([1, 1], dtype=np.uint8))
+        planner.update_cells(xy, np.array([1, 1], dtype=np.uint8))
+        assert_same(p2.plan_batch(s, g, 2, 1024), planner.plan_batch(s, g, 2, 1024))
