@@ -186,30 +186,39 @@ def test_generation_wrap_and_table_wipe(planner, oracle):
 
 
 def test_equal_key_far_path(planner, oracle):
-    """Open grids with the octile heuristic: thousands of equal f values per level.  The far tier is refilled by
-    (x, y) slices and, with more than 256 entries tied at the minimum key, popped directly."""
+    """Maps with the octile heuristic (integer keys): thousands of equal f values per level.  The far tier is
+    refilled by (x, y) slices of one f level and, with more than 256 entries tied at the minimum key, popped directly."""
     rng = np.random.default_rng(8)
-    W, H = 900, 1100
+    # (a) a regular lattice of single-cell obstacles: every obstacle forces neighbours, all costs are symmetric
+    W = H = 640
     occ = np.zeros((W, H), dtype=np.uint8)
-    occ[rng.integers(0, W, 400), rng.integers(0, H, 400)] = 1
+    occ[4::4, 4::4] = 1
     free = np.argwhere(occ == 0)
-    n = 200
+    n = 64
+    s = free[rng.integers(0, len(free), n)].astype(np.int32)
+    g = free[rng.integers(0, len(free), n)].astype(np.int32)
+    s[:8] = [[1, 1], [1, 638], [320, 1], [2, 321], [638, 638], [7, 9], [1, 1], [637, 2]]
+    g[:8] = [[638, 638], [638, 1], [321, 638], [637, 322], [1, 1], [630, 9], [638, 2], [2, 637]]
+    planner.set_grid_occ(occ)
+    res = planner.plan_batch(s, g, 1, 4096)
+    tm = planner.timing()
+    print("equal-key lattice", tm)
+    assert tm["far_refills"] > 0, tm
+    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 4096))
+    res = planner.plan_batch(s, g, 2, 4096)
+    print("equal-key lattice h2", planner.timing())
+    assert_same(res, oracle_csr(oracle, occ, s, g, 2, 4096))
+    # (b) a large sparse map (1 % obstacles), long queries
+    W, H = 900, 2500
+    occ = (rng.random((W, H)) < 0.01).astype(np.uint8)
+    free = np.argwhere(occ == 0)
+    n = 300
     s = free[rng.integers(0, len(free), n)].astype(np.int32)
     g = free[rng.integers(0, len(free), n)].astype(np.int32)
     planner.set_grid_occ(occ)
-    res = planner.plan_batch(s, g, 1, 2048)
-    tm = planner.timing()
-    print("equal-key", tm)
-    assert tm["far_refills"] > 0, tm
-    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 2048))
-    # all-equal keys: an empty grid where every node of a level ties (f constant along the diagonal band)
-    occ2 = np.zeros((700, 700), dtype=np.uint8)
-    s2 = np.tile(np.array([[0, 350]], dtype=np.int32), (8, 1))
-    g2 = np.array([[699, 350 + k] for k in range(8)], dtype=np.int32)
-    planner.set_grid_occ(occ2)
-    res2 = planner.plan_batch(s2, g2, 1, 2048)
-    print("equal-key empty grid", planner.timing())
-    assert_same(res2, oracle_csr(oracle, occ2, s2, g2, 1, 2048))
+    res = planner.plan_batch(s, g, 1, 4096)
+    print("equal-key sparse", planner.timing())
+    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 4096))
 
 
 # ------------------------------------------------------------------ device-buffer adoption, multi-process path
