@@ -144,6 +144,10 @@ struct fxjps {
     bool have_grid = false;
     fxjps_timing_t timing{};
     int64_t last_nq = 0;
+    // persistent query set of the streaming-replan entry points (fxjps_set_queries / fxjps_replan_frame)
+    std::vector<int32_t> q_starts, q_goals;
+    int q_hchoice = 0, q_max_len = 0;
+    bool q_set = false;
     // RCCL (only for n_dev > 1), resolved with dlopen so that a single-GPU
     // deployment does not need librccl at load time
     void* rccl = nullptr;
@@ -945,9 +949,10 @@ int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* ou
     return FXJPS_OK;
 }
 
-int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
-    if (!h) return FXJPS_E_ARG;
-    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_update_cells before fxjps_set_grid");
+namespace {
+// Queue the cell updates and the rebuild of the derived maps on every device's stream (no host wait).
+int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "cell update before fxjps_set_grid");
     if (n < 0 || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
     if (n == 0) return FXJPS_OK;
     // every device applies the same (small) update list; cheaper than re-broadcasting the grid
@@ -963,21 +968,12 @@ int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
         int rc = derive_maps(h, d);
         if (rc) return rc;
     }
-    for (auto& d : h->devs) {
-        HIPCHK(h, hipSetDevice(d.dev));
-        HIPCHK(h, hipStreamSynchronize(d.stream));
-    }
     return FXJPS_OK;
 }
 
-int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq,
-                         int32_t hchoice, int32_t max_path_len, int64_t* out_offsets, int32_t* out_cells_xy,
-                         int64_t cells_capacity, int32_t* out_len, double* out_cost, double* out_seconds_total) {
-    const double t0 = now_s();
-    if (!h) return FXJPS_E_ARG;
-    if (nq > 0 && (!out_offsets || !out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
-    int rc = plan_core(h, starts_xy, goals_xy, nq, hchoice, max_path_len);
-    if (rc) return rc;
+// plan_core's results -> the caller's CSR arrays
+int emit_csr(fxjps_t* h, int64_t nq, int64_t* out_offsets, int32_t* out_cells_xy, int64_t cells_capacity, int32_t* out_len,
+             double* out_cost) {
     int64_t base = 0;
     bool fits = true;
     for (auto& d : h->devs) {
@@ -997,10 +993,67 @@ int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* go
     }
     if (out_offsets) out_offsets[nq] = base;
     h->last_nq = nq;
-    h->timing.total_ms = (now_s() - t0) * 1e3;
-    if (out_seconds_total) *out_seconds_total = now_s() - t0;
     if (!fits) return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, batch needs %lld", (long long)cells_capacity, (long long)base);
     return FXJPS_OK;
+}
+}  // namespace
+
+int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
+    if (!h) return FXJPS_E_ARG;
+    int rc = update_cells_async(h, xy, val, n);
+    if (rc) return rc;
+    for (auto& d : h->devs) {
+        HIPCHK(h, hipSetDevice(d.dev));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
+    }
+    return FXJPS_OK;
+}
+
+int fxjps_set_queries(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq, int32_t hchoice,
+                      int32_t max_path_len) {
+    if (!h) return FXJPS_E_ARG;
+    if (nq < 0 || (nq > 0 && (!starts_xy || !goals_xy))) return fail(h, FXJPS_E_ARG, "bad query arrays");
+    if (hchoice != 1 && hchoice != 2) return fail(h, FXJPS_E_ARG, "hchoice must be 1 or 2 (the reference raises TypeError, jps1.py:188)");
+    if (max_path_len < 1 || max_path_len > (1 << 20)) return fail(h, FXJPS_E_ARG, "max_path_len out of range");
+    h->q_starts.assign(starts_xy, starts_xy + 2 * nq);  // copied: the caller's arrays are not kept
+    h->q_goals.assign(goals_xy, goals_xy + 2 * nq);
+    h->q_hchoice = hchoice;
+    h->q_max_len = max_path_len;
+    h->q_set = true;
+    return FXJPS_OK;
+}
+
+int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n, int64_t* out_offsets, int32_t* out_cells_xy,
+                       int64_t cells_capacity, int32_t* out_len, double* out_cost, double* out_seconds_total) {
+    const double t0 = now_s();
+    if (!h) return FXJPS_E_ARG;
+    if (!h->q_set) return fail(h, FXJPS_E_ARG, "fxjps_replan_frame before fxjps_set_queries");
+    const int64_t nq = (int64_t)h->q_starts.size() / 2;
+    if (nq > 0 && (!out_offsets || !out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
+    // the frame's map update is queued in front of the search on the same streams: the first host wait of the frame
+    // is the one for the search results
+    int rc = update_cells_async(h, xy, val, n);
+    if (rc) return rc;
+    rc = plan_core(h, h->q_starts.data(), h->q_goals.data(), nq, h->q_hchoice, h->q_max_len);
+    if (rc) return rc;
+    rc = emit_csr(h, nq, out_offsets, out_cells_xy, cells_capacity, out_len, out_cost);
+    h->timing.total_ms = (now_s() - t0) * 1e3;
+    if (out_seconds_total) *out_seconds_total = now_s() - t0;
+    return rc;
+}
+
+int fxjps_plan_batch_csr(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq,
+                         int32_t hchoice, int32_t max_path_len, int64_t* out_offsets, int32_t* out_cells_xy,
+                         int64_t cells_capacity, int32_t* out_len, double* out_cost, double* out_seconds_total) {
+    const double t0 = now_s();
+    if (!h) return FXJPS_E_ARG;
+    if (nq > 0 && (!out_offsets || !out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
+    int rc = plan_core(h, starts_xy, goals_xy, nq, hchoice, max_path_len);
+    if (rc) return rc;
+    rc = emit_csr(h, nq, out_offsets, out_cells_xy, cells_capacity, out_len, out_cost);
+    h->timing.total_ms = (now_s() - t0) * 1e3;
+    if (out_seconds_total) *out_seconds_total = now_s() - t0;
+    return rc;
 }
 
 int fxjps_last_cells(fxjps_t* h, int32_t* out_cells_xy, int64_t cells_capacity) {

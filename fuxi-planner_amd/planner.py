@@ -206,6 +206,45 @@ class Planner(object):
         self.last_seconds = secs.value
         return offsets, cells, cost, status
 
+    # -- streaming replan (persistent goals, one call per frame)
+    def set_queries(self, starts, goals, hchoice=2, max_path_len=None):
+        """Store the persistent (start, goal) set that replan_frame plans every frame."""
+        if self.shape is None:
+            raise FxjpsError(_lib.E_NOGRID, "set_queries before set_grid")
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 2)
+        goals = np.ascontiguousarray(goals, dtype=np.int32).reshape(-1, 2)
+        if len(starts) != len(goals):
+            raise ValueError("starts and goals lengths differ")
+        if hchoice not in (1, 2):
+            raise TypeError("unsupported operand type(s) for +: 'float' and 'NoneType' (hchoice must be 1 or 2)")
+        mpl = self.default_max_path_len() if max_path_len is None else int(max_path_len)
+        self._chk(self._L.fxjps_set_queries(self._h, _lib.ptr(starts, C.c_int32), _lib.ptr(goals, C.c_int32), len(starts),
+                                            int(hchoice), mpl))
+        self._nq = len(starts)
+
+    def replan_frame(self, xy=None, val=None):
+        """One frame: apply the cell updates (xy int32[n, 2], val uint8[n]; may be empty), rebuild the maps, plan the
+        stored queries.  -> (offsets, cells, cost, status) as plan_batch."""
+        if xy is None:
+            xy, val = np.zeros((0, 2), np.int32), np.zeros(0, np.uint8)
+        xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
+        if len(val) != len(xy):
+            raise ValueError("xy and val lengths differ")
+        n = self._nq
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        status = np.zeros(n, dtype=np.int32)
+        cost = np.zeros(n, dtype=np.float64)
+        secs = C.c_double(0.0)
+        self._chk(self._L.fxjps_replan_frame(self._h, _lib.ptr(xy, C.c_int32), _lib.ptr(val, C.c_uint8), len(val),
+                                             _lib.ptr(offsets, C.c_int64), None, 0, _lib.ptr(status, C.c_int32),
+                                             _lib.ptr(cost, C.c_double), C.byref(secs)))
+        cells = np.empty((int(offsets[n]), 2), dtype=np.int32)
+        if offsets[n] > 0:
+            self._chk(self._L.fxjps_last_cells(self._h, _lib.ptr(cells, C.c_int32), int(offsets[n])))
+        self.last_seconds = secs.value
+        return offsets, cells, cost, status
+
     def plan(self, start, goal, hchoice=2):
         """plan(start, goal) -> waypoint list [(x, y), ...] (jump points, start and
         goal inclusive); [] when there is no path."""

@@ -131,6 +131,18 @@ int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* ou
  * obstacle) on the resident grid and rebuild the derived maps. */
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
 
+/* Streaming replan with a persistent query set (SURVEY.md 8f, row N4 / BASELINE config 5: the node replans the same
+ * goals tick after tick, scripts/global_planner_ccst.py:476-480).  fxjps_set_queries stores nq (start, goal) pairs,
+ * hchoice and max_path_len in the handle (copied).  fxjps_replan_frame applies one frame of cell updates (as
+ * fxjps_update_cells; n may be 0), rebuilds the derived maps and plans the stored queries against the new grid, all
+ * queued on the device without an intermediate host wait; results as fxjps_plan_batch_csr (fxjps_last_cells and
+ * fxjps_last_timing work the same way).  Every frame is a from-scratch search: bit-identical to set_grid + plan. */
+int fxjps_set_queries(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq, int32_t hchoice,
+                      int32_t max_path_len);
+int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n, int64_t* out_offsets,
+                       int32_t* out_cells_xy, int64_t cells_capacity, int32_t* out_len, double* out_cost,
+                       double* out_seconds_total);
+
 /* Plan nq independent (start, goal) queries against the resident grid.
  *   starts_xy, goals_xy : nq (x, y) pairs
  *   out_cells_xy        : nq * max_path_len (x, y) pairs; query q's jump points

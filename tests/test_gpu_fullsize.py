@@ -130,19 +130,27 @@ def test_config5_frames(planner, oracle):
     keep[s[:, 0], s[:, 1]] = True
     keep[g[:, 0], g[:, 1]] = True
     planner.set_grid_occ(occ)
+    planner.set_queries(s, g, 2, 2048)
+    assert_same(planner.replan_frame(), oracle_csr(oracle, occ, s, g, 2, 2048))  # a frame without updates
     prev = None
     for frame in range(6):
         xy, val = synth.synth_toggles(occ, keep, frame)
         assert len(val) == 2 * int(0.05 * W * H) and (val == 0).sum() == (val == 1).sum()
         assert (occ[xy[:, 0], xy[:, 1]] != val).all() and not keep[xy[:, 0], xy[:, 1]].any()
-        planner.update_cells(xy, val)
+        if frame % 2 == 0:
+            res = planner.replan_frame(xy, val)      # the streaming entry point: update + maps + plan in one call
+        else:
+            planner.update_cells(xy, val)            # ... equals the two separate calls
+            res = planner.plan_batch(s, g, 2, 2048)
         synth.apply_toggles(occ, xy, val)
         assert int(occ.sum()) == int(synth.synth_grid(W, H, 1, 0.20).sum())  # the density stays put
-        res = planner.plan_batch(s, g, 2, 2048)
         assert_same(res, oracle_csr(oracle, occ, s, g, 2, 2048))
         assert prev is None or not np.array_equal(prev, res[2])  # the frames really differ
         prev = res[2].copy()
     assert np.array_equal(planner.get_grid(), occ)
+    # the same stream on a fresh upload of the final grid
+    planner.set_grid_occ(occ)
+    assert_same(planner.plan_batch(s, g, 2, 2048), res)
 
 
 # ------------------------------------------------------------------ cold paths, forced
