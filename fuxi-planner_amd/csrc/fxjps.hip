@@ -121,7 +121,7 @@ struct DevCtx {
     DBuf<uint32_t> d_path, d_order, d_redo;
     DBuf<long long> d_offsets;
     DBuf<unsigned int> d_next;
-    DBuf<unsigned long long> d_counters;
+    DBuf<unsigned long long> d_counters, d_qstat;
     DBuf<uint8_t> d_raw, d_img;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val;
@@ -377,6 +377,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.out_len = d.d_len.p;
     A.out_cost = d.d_cost.p;
     A.out_counters = d.d_counters.p;
+    A.qstat = d.d_qstat.p;  // nullptr unless FXJPS_QSTAT is set
     A.tables = d.tables[pool].p;
     A.far = d.far[pool].p;
     A.log2_buckets = c.log2_buckets;
@@ -426,6 +427,10 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     HIPCHK(h, hipMemcpyAsync(d.d_starts.p, starts + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.d_goals.p, goals + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 32 * sizeof(unsigned long long), d.stream));
+    if (getenv("FXJPS_QSTAT")) {  // diagnostics: per-query start / end time, pops, wavefront (tools/qstat.py)
+        HIPCHK(h, d.d_qstat.ensure((size_t)nq * 4));
+        HIPCHK(h, hipMemsetAsync(d.d_qstat.p, 0, (size_t)nq * 4 * sizeof(unsigned long long), d.stream));
+    }
     uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC;  // every wavefront the chip can hold at once
     if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(fx::WPB, atoi(e)) & ~((uint32_t)fx::WPB - 1u);  // measurement aid
     // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
@@ -704,6 +709,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_offsets.release();
         d.d_next.release();
         d.d_counters.release();
+        d.d_qstat.release();
         d.d_raw.release();
         d.d_img.release();
         d.d_upd_xy.release();
@@ -1126,6 +1132,16 @@ int fxjps_debug_counters(fxjps_t* h, unsigned long long* out32) {
     DevCtx& d = h->devs[0];
     if (!d.h_counters.p) return FXJPS_E_ARG;
     memcpy(out32, d.h_counters.p, 32 * sizeof(unsigned long long));
+    return FXJPS_OK;
+}
+
+// per-query diagnostics of the last batch on device 0 (FXJPS_QSTAT=1): 4 u64 per query (tools only; not in fxjps.h)
+int fxjps_debug_qstat(fxjps_t* h, unsigned long long* out, int64_t nq) {
+    if (!h || !out) return FXJPS_E_ARG;
+    DevCtx& d = h->devs[0];
+    if (!d.d_qstat.p || nq > d.nq) return FXJPS_E_ARG;
+    HIPCHK(h, hipSetDevice(d.dev));
+    HIPCHK(h, hipMemcpy(out, d.d_qstat.p, (size_t)nq * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FXJPS_OK;
 }
 

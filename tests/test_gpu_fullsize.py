@@ -194,10 +194,22 @@ def test_generation_wrap_and_table_wipe(planner, oracle):
 
 
 def test_equal_key_far_path(planner, oracle):
-    """Maps with the octile heuristic (integer keys): thousands of equal f values per level.  The far tier is
-    refilled by (x, y) slices of one f level and, with more than 256 entries tied at the minimum key, popped directly."""
+    """The octile heuristic gives integer keys: hundreds of equal f values per level, which the open list has to split
+    on (x, y) -- in the LDS tier and, on maps whose open lists outgrow it, in the global-memory tier (refills by
+    (x, y) slices of one f level).  (The last resort behind those, a direct pop from the global tier when more than
+    256 entries share one FULL key, needs duplicates of one cell with equal f and direction; no map reaches it.)"""
+    from fuxi_planner_amd import synth
     rng = np.random.default_rng(8)
-    # (a) a regular lattice of single-cell obstacles: every obstacle forces neighbours, all costs are symmetric
+    occ = synth.synth_grid(640, 512, 44, 0.20)
+    s, g = synth.synth_queries(occ, 44, 800)
+    planner.set_grid_occ(occ)
+    res = planner.plan_batch(s, g, 1, 1024)
+    tm = planner.timing()
+    print("equal-key 20%", tm)
+    assert tm["far_refills"] > 100, tm
+    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 1024))
+    # a regular lattice of single-cell obstacles (every obstacle forces neighbours, all costs symmetric) and a large
+    # sparse map: long rays, few nodes, many exact ties
     W = H = 640
     occ = np.zeros((W, H), dtype=np.uint8)
     occ[4::4, 4::4] = 1
@@ -208,15 +220,8 @@ def test_equal_key_far_path(planner, oracle):
     s[:8] = [[1, 1], [1, 638], [320, 1], [2, 321], [638, 638], [7, 9], [1, 1], [637, 2]]
     g[:8] = [[638, 638], [638, 1], [321, 638], [637, 322], [1, 1], [630, 9], [638, 2], [2, 637]]
     planner.set_grid_occ(occ)
-    res = planner.plan_batch(s, g, 1, 4096)
-    tm = planner.timing()
-    print("equal-key lattice", tm)
-    assert tm["far_refills"] > 0, tm
-    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 4096))
-    res = planner.plan_batch(s, g, 2, 4096)
-    print("equal-key lattice h2", planner.timing())
-    assert_same(res, oracle_csr(oracle, occ, s, g, 2, 4096))
-    # (b) a large sparse map (1 % obstacles), long queries
+    for h in (1, 2):
+        assert_same(planner.plan_batch(s, g, h, 4096), oracle_csr(oracle, occ, s, g, h, 4096))
     W, H = 900, 2500
     occ = (rng.random((W, H)) < 0.01).astype(np.uint8)
     free = np.argwhere(occ == 0)
@@ -224,9 +229,7 @@ def test_equal_key_far_path(planner, oracle):
     s = free[rng.integers(0, len(free), n)].astype(np.int32)
     g = free[rng.integers(0, len(free), n)].astype(np.int32)
     planner.set_grid_occ(occ)
-    res = planner.plan_batch(s, g, 1, 4096)
-    print("equal-key sparse", planner.timing())
-    assert_same(res, oracle_csr(oracle, occ, s, g, 1, 4096))
+    assert_same(planner.plan_batch(s, g, 1, 4096), oracle_csr(oracle, occ, s, g, 1, 4096))
 
 
 # ------------------------------------------------------------------ device-buffer adoption, multi-process path
