@@ -104,7 +104,7 @@ struct DevCtx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // grid
-    int W = 0, H = 0, PW = 0, PH = 0, NS = 0, LINES = 0, WORDS = 0;
+    int W = 0, H = 0, PW = 0, PH = 0, NS = 0, LINES = 0, WORDS = 0, tsh = 0;
     DBuf<uint8_t> occ, nb8;
     DBuf<fx::BmWord> bm;
     DBuf<int> comp;
@@ -121,7 +121,11 @@ struct DevCtx {
     DBuf<uint32_t> d_path, d_order, d_redo;
     DBuf<long long> d_offsets;
     DBuf<unsigned int> d_next;
-    DBuf<unsigned long long> d_counters, d_qstat;
+    DBuf<unsigned long long> d_counters, d_qstat, d_qread;
+    std::vector<unsigned long long> h_qread;  // read sets of the resident results (streaming replan)
+    std::vector<uint8_t> h_sel;   // mode 2: which queries of the shard are searched again this frame
+    int mode = 0;                 // 0 plain batch, 1 search everything and record read sets, 2 the same for h_sel only
+    int64_t nrun = 0;             // queries handed to the search kernel
     DBuf<uint8_t> d_raw, d_img;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val;
@@ -148,6 +152,9 @@ struct fxjps {
     std::vector<int32_t> q_starts, q_goals;
     int q_hchoice = 0, q_max_len = 0;
     bool q_set = false;
+    // true while the device result buffers and the host read sets of every device describe the stored queries on the
+    // resident grid: then a frame only searches the queries whose read set its cell updates touch
+    bool q_results_valid = false;
     // RCCL (only for n_dev > 1), resolved with dlopen so that a single-GPU
     // deployment does not need librccl at load time
     void* rccl = nullptr;
@@ -231,6 +238,7 @@ GridDev grid_of(const DevCtx& d) {
     G.NS = d.NS;
     G.LINES = d.LINES;
     G.WORDS = d.WORDS;
+    G.tsh = d.tsh;
     return G;
 }
 
@@ -267,6 +275,8 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     d.NS = (d.PH + 63) & ~63;
     d.LINES = std::max(d.PW, d.PH);
     d.WORDS = (std::max(d.PW, d.PH) + 63) / 64;
+    d.tsh = 0;  // read-set tiles (streaming replan): at most 64 x 64 of them cover the grid
+    while (((std::max(W, H) - 1) >> d.tsh) > 63) d.tsh++;
     HIPCHK(h, d.occ.ensure((size_t)W * H));
     HIPCHK(h, d.comp.ensure((size_t)W * H));
     HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
@@ -364,7 +374,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     return FXJPS_OK;
 }
 
-int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32_t nrun, int hchoice, int max_len) {
+int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32_t nrun, int hchoice, int max_len, bool track = false) {
     const ScratchCfg& c = d.cfg[pool];
     SearchArgs A;
     A.G = grid_of(d);
@@ -378,6 +388,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.out_cost = d.d_cost.p;
     A.out_counters = d.d_counters.p;
     A.qstat = d.d_qstat.p;  // nullptr unless FXJPS_QSTAT is set
+    A.qread = track ? d.d_qread.p : nullptr;
     A.tables = d.tables[pool].p;
     A.far = d.far[pool].p;
     A.log2_buckets = c.log2_buckets;
@@ -398,10 +409,16 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
-    if (hchoice == 1)
-        hipLaunchKernelGGL(fx::k_search<1>, grid, block, 0, d.stream, A);
-    else
-        hipLaunchKernelGGL(fx::k_search<2>, grid, block, 0, d.stream, A);
+    if (track) {  // the instantiation that records each search's read set (fxjps_replan_frame)
+        if (hchoice == 1)
+            hipLaunchKernelGGL((fx::k_search<1, true>), grid, block, 0, d.stream, A);
+        else
+            hipLaunchKernelGGL((fx::k_search<2, true>), grid, block, 0, d.stream, A);
+    } else if (hchoice == 1) {
+        hipLaunchKernelGGL((fx::k_search<1, false>), grid, block, 0, d.stream, A);
+    } else {
+        hipLaunchKernelGGL((fx::k_search<2, false>), grid, block, 0, d.stream, A);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(d.ev1, d.stream));
     d.launches++;
@@ -417,6 +434,7 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     d.kernel_ms = 0;
     d.launches = 0;
     d.retried = 0;
+    d.nrun = 0;
     if (nq == 0) return FXJPS_OK;
     HIPCHK(h, d.d_starts.ensure((size_t)nq * 2));
     HIPCHK(h, d.d_goals.ensure((size_t)nq * 2));
@@ -451,17 +469,29 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
             const int64_t dx = std::llabs((int64_t)S[2 * i] - G[2 * i]), dy = std::llabs((int64_t)S[2 * i + 1] - G[2 * i + 1]);
             return (uint32_t)std::min<int64_t>(std::max(dx, dy), 8191);
         };
-        for (int64_t i = 0; i < nq; i++) head[8191 - key(i) + 1]++;
+        const bool subset = d.mode == 2;  // streaming replan: only the queries whose read set was touched
+        auto in = [&](int64_t i) -> bool { return !subset || d.h_sel[(size_t)i] != 0; };
+        for (int64_t i = 0; i < nq; i++)
+            if (in(i)) head[8191 - key(i) + 1]++;
         for (int k = 1; k < 8194; k++) head[k] += head[k - 1];
-        for (int64_t i = 0; i < nq; i++) d.h_order[head[8191 - key(i)]++] = (uint32_t)i;
+        d.nrun = head[8193];
+        for (int64_t i = 0; i < nq; i++)
+            if (in(i)) d.h_order[head[8191 - key(i)]++] = (uint32_t)i;
         HIPCHK(h, d.d_order.ensure((size_t)nq));
-        HIPCHK(h, hipMemcpyAsync(d.d_order.p, d.h_order.data(), (size_t)nq * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+        if (d.nrun > 0)
+            HIPCHK(h, hipMemcpyAsync(d.d_order.p, d.h_order.data(), (size_t)d.nrun * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
     }
+    if (d.mode != 0) {  // read-set bitmaps: 128 x u64 per query, zero for queries that never searched
+        const size_t had = d.d_qread.cap;
+        HIPCHK(h, d.d_qread.ensure((size_t)nq * 128));
+        if (d.d_qread.cap != had) HIPCHK(h, hipMemsetAsync(d.d_qread.p, 0, d.d_qread.cap * sizeof(unsigned long long), d.stream));
+    }
+    if (d.nrun == 0) return FXJPS_OK;  // every result of the previous frame is still valid
     DBG("run_shard nq=%lld: inputs queued", (long long)nq);
-    int rc = ensure_pool(h, d, 0, (uint32_t)std::min<int64_t>(full, (nq + 3) & ~3ll));
+    int rc = ensure_pool(h, d, 0, (uint32_t)std::min<int64_t>(full, (d.nrun + 3) & ~3ll));
     if (rc) return rc;
     DBG("pool ready");
-    rc = launch_search(h, d, 0, d.d_order.p, (uint32_t)nq, hchoice, max_len);
+    rc = launch_search(h, d, 0, d.d_order.p, (uint32_t)d.nrun, hchoice, max_len, d.mode != 0);
     if (rc) return rc;
     return FXJPS_OK;
 }
@@ -477,8 +507,10 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     HIPCHK(h, hipStreamSynchronize(d.stream));
     DBG("search kernel done");
     float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
-    d.kernel_ms += ms;
+    if (d.launches > 0) {
+        HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+        d.kernel_ms += ms;
+    }
     std::vector<uint32_t> redo;
     for (int64_t i = 0; i < nq; i++)
         if (d.h_len.p[i] <= fx::QI_TABLE_FULL) redo.push_back((uint32_t)i);
@@ -489,7 +521,7 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
         HIPCHK(h, d.d_redo.ensure(redo.size()));
         HIPCHK(h, hipMemcpyAsync(d.d_redo.p, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
         HIPCHK(h, hipStreamSynchronize(d.stream));  // `redo` is pageable host memory
-        rc = launch_search(h, d, 1, d.d_redo.p, (uint32_t)redo.size(), hchoice, max_len);
+        rc = launch_search(h, d, 1, d.d_redo.p, (uint32_t)redo.size(), hchoice, max_len, d.mode != 0);
         if (rc) return rc;
         HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
         HIPCHK(h, hipStreamSynchronize(d.stream));
@@ -502,6 +534,10 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     HIPCHK(h, hipMemcpyAsync(d.h_offsets.p, d.d_offsets.p, ((size_t)nq + 1) * sizeof(long long), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.h_cost.p, d.d_cost.p, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    if (d.mode != 0 && d.launches > 0) {  // the read sets of what ran (the rest of the buffer is unchanged)
+        d.h_qread.resize((size_t)nq * 128);
+        HIPCHK(h, hipMemcpyAsync(d.h_qread.data(), d.d_qread.p, (size_t)nq * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    }
     HIPCHK(h, hipStreamSynchronize(d.stream));
     const long long total = d.h_offsets.p[nq];
     DBG("scan done, %lld cells", total);
@@ -521,7 +557,7 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     return FXJPS_OK;
 }
 
-int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq, int hchoice, int max_len) {
+int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq, int hchoice, int max_len, int mode = 0) {
     if (!h) return FXJPS_E_ARG;
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_plan_batch before fxjps_set_grid");
     if (nq < 0 || (nq > 0 && (!starts || !goals))) return fail(h, FXJPS_E_ARG, "bad query arrays");
@@ -533,7 +569,9 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     for (int r = 0; r < nd; r++) {  // contiguous shards: SURVEY 8(e)
         h->devs[r].q0 = nq * r / nd;
         h->devs[r].nq = nq * (r + 1) / nd - h->devs[r].q0;
+        h->devs[r].mode = mode;
     }
+    h->q_results_valid = false;  // (fxjps_replan_frame sets it again once its frame is complete)
     int rc = FXJPS_OK;
     for (int r = 0; r < nd && !rc; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
     for (int r = 0; r < nd && !rc; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
@@ -558,6 +596,7 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     T.far_refills = 0;
     T.slow_pops = 0;
     T.table_wipes = 0;
+    T.reused = 0;
     for (auto& d : h->devs) {
         T.search_kernel_ms = std::max(T.search_kernel_ms, d.kernel_ms);
         T.search_launches += d.launches;
@@ -716,6 +755,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_next.release();
         d.d_counters.release();
         d.d_qstat.release();
+        d.d_qread.release();
         d.d_raw.release();
         d.d_img.release();
         d.d_upd_xy.release();
@@ -738,6 +778,7 @@ int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
     if (!h) return FXJPS_E_ARG;
     if (!occ || W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
     h->have_grid = false;
+    h->q_results_valid = false;
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, W, H);
         if (rc) return rc;
@@ -756,6 +797,7 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
     if (!h) return FXJPS_E_ARG;
     if (!d_occ || W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
     h->have_grid = false;
+    h->q_results_valid = false;
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, W, H);
         if (rc) return rc;
@@ -787,6 +829,7 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
     const long long H1 = std::max<long long>(std::max<long long>(H0, gy), sy) + dy + 4ll * ifa;
     if (W1 > 8190 || H1 > 8190) return fail(h, FXJPS_E_ARG, "prepared grid %lldx%lld exceeds 8190 cells a side", W1, H1);
     h->have_grid = false;
+    h->q_results_valid = false;
     for (auto& d : h->devs) {
         HIPCHK(h, hipSetDevice(d.dev));
         HIPCHK(h, d.d_raw.ensure((size_t)W0 * H0));
@@ -925,6 +968,7 @@ int fxjps_set_grid_image(fxjps_t* h, const uint8_t* gray, int32_t rows, int32_t 
     if (!h) return FXJPS_E_ARG;
     if (!gray || rows < 1 || cols < 1 || rows > 8190 || cols > 8190) return fail(h, FXJPS_E_ARG, "image must be 1..8190 pixels a side");
     h->have_grid = false;
+    h->q_results_valid = false;
     const size_t n = (size_t)rows * cols;
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, cols, rows);  // map_pre = img[::-1].T: W = image columns, H = image rows   :182
@@ -1012,6 +1056,7 @@ int emit_csr(fxjps_t* h, int64_t nq, int64_t* out_offsets, int32_t* out_cells_xy
 
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
     if (!h) return FXJPS_E_ARG;
+    h->q_results_valid = false;  // the grid changes behind the stored results
     int rc = update_cells_async(h, xy, val, n);
     if (rc) return rc;
     for (auto& d : h->devs) {
@@ -1032,6 +1077,7 @@ int fxjps_set_queries(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals
     h->q_hchoice = hchoice;
     h->q_max_len = max_path_len;
     h->q_set = true;
+    h->q_results_valid = false;
     return FXJPS_OK;
 }
 
@@ -1042,12 +1088,59 @@ int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     if (!h->q_set) return fail(h, FXJPS_E_ARG, "fxjps_replan_frame before fxjps_set_queries");
     const int64_t nq = (int64_t)h->q_starts.size() / 2;
     if (nq > 0 && (!out_offsets || !out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
+    // ---- exact reuse.  Which read-set tiles does this frame's update touch?  Derived data of a cell depends on the
+    // occupancy within Chebyshev distance 1, so every changed cell marks the tiles of its 3 x 3 neighbourhood; a
+    // stored result whose read set (see ReadSet in the kernels) misses all of them is what a from-scratch search
+    // on the new grid would return, bit for bit, and is not searched again.
+    static const bool allow_reuse = !(getenv("FXJPS_REPLAN_REUSE") && atoi(getenv("FXJPS_REPLAN_REUSE")) == 0);
+    DevCtx& d0 = h->devs[0];
+    unsigned long long DX[64], DY[64];  // DX[y tile]: bit per x tile, DY[x tile]: bit per y tile
+    memset(DX, 0, sizeof(DX));
+    memset(DY, 0, sizeof(DY));
+    for (int64_t i = 0; i < n; i++) {
+        const int x = xy[2 * i], y = xy[2 * i + 1];
+        if (x < 0 || y < 0 || x >= d0.W || y >= d0.H) continue;  // (k_update_cells ignores it as well)
+        const int tx0 = std::max(x - 1, 0) >> d0.tsh, tx1 = std::min(x + 1, d0.W - 1) >> d0.tsh;
+        const int ty0 = std::max(y - 1, 0) >> d0.tsh, ty1 = std::min(y + 1, d0.H - 1) >> d0.tsh;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                DX[ty] |= 1ull << tx;
+                DY[tx] |= 1ull << ty;
+            }
+    }
+    int64_t touched = 0, tiles = (int64_t)(((d0.W - 1) >> d0.tsh) + 1) * (((d0.H - 1) >> d0.tsh) + 1);
+    for (int t = 0; t < 64; t++) touched += __builtin_popcountll(DX[t]);
+    // Recording read sets costs a few instructions per ray; it pays only when the next frame can reuse something.
+    // A frame that touches most tiles (config 5: 10 % of all cells) leaves nothing to reuse: it runs untracked.
+    const bool track = allow_reuse && 2 * touched <= tiles;
+    int mode = track ? 1 : 0;
+    int64_t reused = 0;
+    if (track && h->q_results_valid) {
+        mode = 2;
+        for (auto& d : h->devs) {
+            d.h_sel.assign((size_t)d.nq, 1);  // (the shards are those of the previous frame: same query set)
+            const int64_t dn = d.nq;
+            for (int64_t q = 0; q < dn; q++) {
+                if (d.h_len.p[q] <= 0) continue;  // no path / an error code: depends on more than a read set, search again
+                const unsigned long long* bx = d.h_qread.data() + (size_t)q * 128;
+                const unsigned long long* by = bx + 64;
+                unsigned long long hit = 0;
+                for (int t = 0; t < 64; t++) hit |= (bx[t] & DX[t]) | (by[t] & DY[t]);
+                if (!hit) {
+                    d.h_sel[(size_t)q] = 0;
+                    reused++;
+                }
+            }
+        }
+    }
     // the frame's map update is queued in front of the search on the same streams: the first host wait of the frame
     // is the one for the search results
     int rc = update_cells_async(h, xy, val, n);
     if (rc) return rc;
-    rc = plan_core(h, h->q_starts.data(), h->q_goals.data(), nq, h->q_hchoice, h->q_max_len);
+    rc = plan_core(h, h->q_starts.data(), h->q_goals.data(), nq, h->q_hchoice, h->q_max_len, mode);
     if (rc) return rc;
+    h->q_results_valid = track;
+    h->timing.reused = reused;
     rc = emit_csr(h, nq, out_offsets, out_cells_xy, cells_capacity, out_len, out_cost);
     h->timing.total_ms = (now_s() - t0) * 1e3;
     if (out_seconds_total) *out_seconds_total = now_s() - t0;

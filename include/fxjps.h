@@ -136,7 +136,12 @@ int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
  * hchoice and max_path_len in the handle (copied).  fxjps_replan_frame applies one frame of cell updates (as
  * fxjps_update_cells; n may be 0), rebuilds the derived maps and plans the stored queries against the new grid, all
  * queued on the device without an intermediate host wait; results as fxjps_plan_batch_csr (fxjps_last_cells and
- * fxjps_last_timing work the same way).  Every frame is a from-scratch search: bit-identical to set_grid + plan. */
+ * fxjps_last_timing work the same way).  Results are bit-identical to set_grid + plan on the updated grid.  Exact
+ * reuse: every search records its read set (which of at most 64 x 64 grid tiles hold a cell whose derived data it
+ * read); a stored result whose read set no updated cell, nor any of its 8 neighbours, falls into is what a
+ * from-scratch search would return and is handed back without searching (fxjps_timing_t.reused counts them).  Any
+ * other call that changes the grid or the device result buffers (set_grid*, update_cells, plan_batch*) drops the
+ * stored results; FXJPS_REPLAN_REUSE=0 in the environment turns the reuse off. */
 int fxjps_set_queries(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq, int32_t hchoice,
                       int32_t max_path_len);
 int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n, int64_t* out_offsets,
@@ -182,6 +187,7 @@ typedef struct fxjps_timing {
     int64_t far_refills;     /* open-list refills from the global-memory tier */
     int64_t slow_pops;       /* pops taken straight from the global-memory tier (> 256 entries tied at the minimum key) */
     int64_t table_wipes;     /* visited-table wipes after a wavefront's generation counter wrapped (every 63 searches) */
+    int64_t reused;          /* fxjps_replan_frame: stored results returned without a search (their read set was untouched) */
 } fxjps_timing_t;
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
 

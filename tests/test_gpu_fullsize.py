@@ -153,6 +153,59 @@ def test_config5_frames(planner, oracle):
     assert_same(planner.plan_batch(s, g, 2, 2048), res)
 
 
+def test_streaming_exact_reuse(planner, oracle):
+    """fxjps_replan_frame with sparse / local updates: results whose read set the update misses are returned without
+    a search -- and every frame still equals the oracle's from-scratch answer on the updated grid, bit for bit."""
+    from fuxi_planner_amd import synth
+    rng = np.random.default_rng(2026)
+    total_reused = 0
+    for (W, H, dens, nq, h, frames) in [(1024, 1024, 0.20, 600, 2, 10), (700, 333, 0.15, 400, 1, 8), (2100, 1500, 0.20, 300, 2, 6),
+                                         (64, 64, 0.2, 200, 2, 6), (5000, 130, 0.1, 150, 2, 4)]:
+        occ = (rng.random((W, H)) < dens).astype(np.uint8)
+        free = np.argwhere(occ == 0)
+        s = free[rng.integers(0, len(free), nq)].astype(np.int32)
+        g = free[rng.integers(0, len(free), nq)].astype(np.int32)
+        # short queries too: most of their read sets stay away from the updates
+        g[::2] = np.clip(s[::2] + rng.integers(-40, 41, (len(s[::2]), 2)), 0, [W - 1, H - 1]).astype(np.int32)
+        mpl = 8192
+        planner.set_grid_occ(occ)
+        planner.set_queries(s, g, h, mpl)
+        assert_same(planner.replan_frame(), oracle_csr(oracle, occ, s, g, h, mpl))
+        assert planner.timing()["reused"] == 0
+        for f in range(frames):
+            kind = f % 4
+            if kind == 0:    # a sensor footprint: a small window, every cell re-observed
+                x0, y0 = int(rng.integers(0, max(W - 24, 1))), int(rng.integers(0, max(H - 24, 1)))
+                xs, ys = np.meshgrid(np.arange(x0, min(x0 + 24, W)), np.arange(y0, min(y0 + 24, H)), indexing="ij")
+                xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+                val = (rng.random(len(xy)) < dens).astype(np.uint8)
+            elif kind == 1:  # a handful of scattered cells
+                k = int(rng.integers(1, 12))
+                xy = np.stack([rng.integers(0, W, k), rng.integers(0, H, k)], 1).astype(np.int32)
+                val = (1 - occ[xy[:, 0], xy[:, 1]]).astype(np.uint8)
+            elif kind == 2:  # an update that changes nothing (same values) plus one real change on a path
+                xy = np.stack([rng.integers(0, W, 50), rng.integers(0, H, 50)], 1).astype(np.int32)
+                val = occ[xy[:, 0], xy[:, 1]].astype(np.uint8)
+                xy = np.concatenate([xy, s[:1] + [[1, 0]]]).astype(np.int32)
+                xy[-1] = np.clip(xy[-1], 0, [W - 1, H - 1])
+                val = np.concatenate([val, [1 - occ[xy[-1, 0], xy[-1, 1]]]]).astype(np.uint8)
+            else:            # an empty frame: everything is reused
+                xy, val = np.zeros((0, 2), np.int32), np.zeros(0, np.uint8)
+            res = planner.replan_frame(xy, val)
+            tm = planner.timing()
+            occ[xy[:, 0], xy[:, 1]] = val
+            assert_same(res, oracle_csr(oracle, occ, s, g, h, mpl)), (W, H, f)
+            if kind == 3:
+                assert tm["reused"] == int((res[3] > 0).sum()), tm  # (queries without a path are always searched again)
+            total_reused += tm["reused"]
+        # a direct update drops the stored results: the next frame searches everything
+        planner.update_cells(np.array([[0, 0]], np.int32), np.array([occ[0, 0]], np.uint8))
+        planner.replan_frame()
+        assert planner.timing()["reused"] == 0
+    print("streaming reuse: %d results returned without a search" % total_reused)
+    assert total_reused > 2000
+
+
 # ------------------------------------------------------------------ cold paths, forced
 def test_scratch_overflow_retries_on_the_large_pool(planner, oracle):
     """A visited table of 2^8 entries / a 64-entry far tier: most queries outgrow the first pool (QI_TABLE_FULL,

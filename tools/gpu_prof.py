@@ -18,6 +18,10 @@ p.set_grid_occ(occ)
 names = ["take batch", "c:wait+probe_eval", "c:write+push+merge", "x:dirs+issue", "x:eval+diag", "x:more+bcast", "c:math+nvalid", "c:hazard", "R/M/far refills", "looptop"]
 for nq in nqs:
     s, g = synth.synth_queries(occ, 1 if W == 1024 else 2, nq)
+    if os.environ.get("FX_QIDS"):  # only these queries of the stream (e.g. one heavy query on an idle chip)
+        ids = [int(v) for v in os.environ["FX_QIDS"].split(",")]
+        s, g = s[ids], g[ids]
+        nq = len(ids)
     for rep in range(2):
         t = time.time(); off, cells, cost, st = p.plan_batch(s, g, int(os.environ.get("FX_HC", "2")), 1024 if W == 1024 else 4096); dt = time.time() - t
     tm = p.timing()
@@ -30,6 +34,8 @@ for nq in nqs:
         print("   diagonal rounds %.2f / batch, rays in flight %.1f / round" % (c[18] / c[4], c[19] / c[18]), flush=True)
     if c[4] and c[20]:
         print("   R refills: one per %.1f batches, %.1f entries each, %.2f aiming rounds each, exact sort in %.1f %%" % (c[4] / c[20], c[23] / c[20], c[21] / c[20], 100.0 * c[22] / c[20]), flush=True)
+    if c[4]:
+        if c[26]: print("   far refill passes %d, entries scanned per pass %.0f, passes per refill %.2f" % (c[26], c[27] / c[26], c[26] / max(c[2], 1)), flush=True)
     if c[4]:
         print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
     tot = sum(c[8:18])
