@@ -11,7 +11,8 @@ generator fuxi-planner_amd/synth.py):
     c4shard  one GPU's share of BASELINE config 4: 1024^2, 125 000 queries
     c4       BASELINE config 4 itself: 1 000 000 queries split over the N ranks (strong scaling)
     c5       BASELINE config 5, streaming replan: a step is one frame = toggle 10 % of the cells + rebuild the maps +
-             plan the 1 000 persistent queries (SURVEY 8d toggle stream); c5low = the same with 0.1 % toggles
+             plan the 1 000 persistent queries (SURVEY 8d toggle stream); c5low = the same with 0.1 % toggles;
+             c5local = one 64 x 64 window re-observed per frame (the exact-reuse case of fxjps_replan_frame)
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
@@ -52,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local"])
     ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
@@ -116,7 +117,7 @@ def main():
         keep[goals[:, 0], goals[:, 1]] = True
         g = occ.copy()
         for fr in range(a.warmup + a.steps):
-            xy, val = synth.synth_toggles(g, keep, fr, wl["toggle_frac"], wl["toggle_seed"])
+            xy, val = synth.frame_update(g, keep, fr, wl)
             synth.apply_toggles(g, xy, val)
             frames.append((xy, val))
 
@@ -145,10 +146,12 @@ def main():
     kernel_ms = []
     status = None
     retried = 0
+    reused = 0
     for i in range(a.steps):
         status, tm = step(a.warmup + i)
         kernel_ms.append(tm["search_kernel_ms"])
         retried += tm["retried"]
+        reused += tm["reused"]
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -207,7 +210,8 @@ def main():
         }
         if streaming:
             out["config"].update({"frames_per_s": a.steps / elapsed, "target_frames_per_s": 60,
-                                  "cells_toggled_per_frame": int(len(frames[0][1]))})
+                                  "cells_sent_per_frame": int(len(frames[0][1])),
+                                  "results_reused_per_frame": reused / a.steps})
         if world == 1 and not a.inlib and not a.no_cpu_baseline:
             from oracle import oracle  # checker used as the CPU baseline ("port"), never by the planner
             ns = min(a.cpu_sample or wl.get("cpu_sample", nq), n_local)

@@ -95,6 +95,38 @@ def synth_toggles(occ, keep, frame, frac=0.05, seed=5):
     return xy, np.concatenate(out_val)
 
 
+def synth_local_update(occ, keep, frame, win=64, p=0.20, seed=5):
+    """Frame update of the local-churn streaming variant (c5local): the map changes where the vehicle looks.  A
+    win x win window, its corner moving deterministically with the frame index, is re-observed: every cell of it
+    (query end points excepted) is sent with a fresh value drawn from the counter-based PRNG keyed by the frame.
+
+        fkey = splitmix64(splitmix64(seed ^ 0x4C4F43414C) ^ frame);   x0 = (37 * frame * win / 8) mod (W - win),
+        y0 = (91 * frame * win / 8) mod (H - win);   value(cell) = (splitmix64(fkey ^ (x*H + y)) >> 32) < floor(p * 2^32)
+
+    -> (xy int32[k, 2], val uint8[k]); `occ` is not modified."""
+    occ = np.asarray(occ)
+    W, H = occ.shape
+    win = min(win, W, H)
+    x0 = (37 * frame * win // 8) % max(W - win, 1)
+    y0 = (91 * frame * win // 8) % max(H - win, 1)
+    fkey = splitmix64(np.array([splitmix64(np.array([np.uint64(seed) ^ np.uint64(0x4C4F43414C)], dtype=np.uint64))[0]
+                                ^ np.uint64(frame)], dtype=np.uint64))[0]
+    xs, ys = np.meshgrid(np.arange(x0, x0 + win), np.arange(y0, y0 + win), indexing="ij")
+    xs, ys = xs.ravel(), ys.ravel()
+    m = ~np.asarray(keep, dtype=bool)[xs, ys]
+    xs, ys = xs[m], ys[m]
+    r = splitmix64(fkey ^ (xs.astype(np.uint64) * np.uint64(H) + ys.astype(np.uint64)))
+    val = ((r >> np.uint64(32)) < np.uint64(int(np.floor(p * 4294967296.0)))).astype(np.uint8)
+    return np.stack([xs, ys], 1).astype(np.int32), val
+
+
+def frame_update(occ, keep, frame, wl):
+    """The frame update a streaming workload of workloads.json asks for."""
+    if wl.get("toggle_mode") == "local":
+        return synth_local_update(occ, keep, frame, wl.get("window", 64), wl["p"], wl["toggle_seed"])
+    return synth_toggles(occ, keep, frame, wl["toggle_frac"], wl["toggle_seed"])
+
+
 def apply_toggles(occ, xy, val):
     occ[xy[:, 0], xy[:, 1]] = val
     return occ

@@ -35,7 +35,10 @@ WORKLOADS = {
                         "free cells occupied (10% of the cells toggled, SURVEY 8d splitmix stream, seed 5), 1000 persistent queries (qseed 5) "
                         "replanned every frame, target 60 frames/s"),
     "c5low": dict(C2, qseed=5, nq=1000, max_path_len=2048, toggle_frac=0.0005, toggle_seed=5, frames=40,
-                  describe="config 5 with 0.1% of the cells toggled per frame (low-churn variant: the ROS node's real ticks)"),
+                  describe="config 5 with 0.1% of the cells toggled per frame, scattered uniformly over the map (low churn, but no locality)"),
+    "c5local": dict(C2, qseed=5, nq=1000, max_path_len=2048, toggle_frac=0.0, toggle_mode="local", window=64, toggle_seed=5, frames=40,
+                    describe="config 5 with local churn (the ROS node's ticks: the map changes where the vehicle looks): per frame one 64x64 "
+                             "window, moving with the frame index, is re-observed (all its cells sent, fresh 20% values), 1000 persistent queries"),
 }
 NT = min(os.cpu_count() or 8, 256)
 
@@ -47,7 +50,7 @@ def count(occ, s, g, h, mpl, nthreads=NT):
 
 
 def main():
-    which = sys.argv[1:] or ["c2", "c2h1", "c4shard", "c3", "c5", "c5low"]
+    which = sys.argv[1:] or ["c2", "c2h1", "c4shard", "c3", "c5", "c5low", "c5local"]
     try:
         with open(OUT) as f:
             out = json.load(f)
@@ -66,7 +69,7 @@ def main():
             keep[g[:, 0], g[:, 1]] = True
             per, reach = [], []
             for fr in range(w["frames"]):
-                xy, val = synth.synth_toggles(occ, keep, fr, w["toggle_frac"], w["toggle_seed"])
+                xy, val = synth.frame_update(occ, keep, fr, w)
                 synth.apply_toggles(occ, xy, val)
                 c, ln = count(occ, s, g, w["hchoice"], w["max_path_len"])
                 per.append(c["algorithmic_bytes"])
