@@ -399,13 +399,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
     waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
     waves = std::min<uint32_t>(waves, c.nwaves);
-    // scheduling policy (see k_search): first round by wavefront age, priorities by position in the order
-    int sched = 3;
-    if (const char* e = getenv("FXJPS_SCHED")) sched = atoi(e);  // measurement aid: bit 0 age assignment, bit 1 priorities
-    A.sched_cols = (sched & 1) ? (uint32_t)std::max(1, d.n_cu) : 0u;
-    A.sched_prio = (sched & 2) ? 1u : 0u;
-    const unsigned int next0 = A.sched_cols ? waves : 0u;  // the first round covers the query positions [0, waves)
-    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d.d_next.p, (int)next0, 1, d.stream));
+    HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
     const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
