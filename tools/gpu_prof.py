@@ -35,7 +35,8 @@ for nq in nqs:
     if c[4] and c[20]:
         print("   R refills: one per %.1f batches, %.1f entries each, %.2f aiming rounds each, exact sort in %.1f %%" % (c[4] / c[20], c[23] / c[20], c[21] / c[20], 100.0 * c[22] / c[20]), flush=True)
     if c[4]:
-        if c[26]: print("   far refill passes %d, entries scanned per pass %.0f, passes per refill %.2f" % (c[26], c[27] / c[26], c[26] / max(c[2], 1)), flush=True)
+        if c[29]: print("   R refill: %.0f cycles each (%d of them)" % (c[28] / c[29], c[29]), flush=True)
+        if c[26]: print("   far refill passes %d, entries scanned per pass %.0f, passes per refill %.2f, cycles per pass %.0f" % (c[26], c[27] / c[26], c[26] / max(c[2], 1), c[30] / c[26]), flush=True)
     if c[4]:
         print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
     tot = sum(c[8:18])
