@@ -100,6 +100,7 @@ struct ScratchCfg {
 struct DevCtx {
     int dev = -1;
     int n_cu = 256;
+    int share = 1;  // contexts of this handle on the same physical device (they split its memory and wavefront slots)
     size_t mem_total = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -305,8 +306,8 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         // queries fill half of a cells/4 table, where one 4-slot bucket in seven is full and the node that meets it
         // is committed by the slow general form (config 2: 152.9 -> 146.9 ms per 10 000 queries).
         {
-            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC;
-            const uint64_t cap = d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30);
+            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC / (uint64_t)d.share;
+            const uint64_t cap = (d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30)) / (uint64_t)d.share;
             uint32_t shift = 2;
             if (const char* e = getenv("FXJPS_TABLE_SHIFT")) shift = (uint32_t)std::max(0, atoi(e));  // measurement aid
             while (shift > 0 && full * (((uint64_t)19 << (l2e + shift))) > cap) shift--;  // 16-byte entries + the far tier (an eighth as many 18-byte entries)
@@ -329,7 +330,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
     // Memory budget.  Pool 0 may take 60 % of the device; pool 1 (allocated while pool 0 stays resident) is sized
     // from what is free right now plus what it already holds, so that the two pools share one budget.
-    size_t budget = d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30);
+    size_t budget = (d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30)) / (size_t)d.share;
     if (pool == 1) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -449,7 +450,8 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
         HIPCHK(h, d.d_qstat.ensure((size_t)nq * 4));
         HIPCHK(h, hipMemsetAsync(d.d_qstat.p, 0, (size_t)nq * 4 * sizeof(unsigned long long), d.stream));
     }
-    uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC;  // every wavefront the chip can hold at once
+    uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC / (uint32_t)d.share;  // every wavefront the chip can hold at once
+    full = std::max<uint32_t>(full & ~((uint32_t)fx::WPB - 1u), (uint32_t)fx::WPB);
     if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(fx::WPB, atoi(e)) & ~((uint32_t)fx::WPB - 1u);  // measurement aid
     // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
     // on the config-2 workload), so far-apart queries are handed out first and the short ones fill
@@ -614,6 +616,25 @@ typedef int (*nccl_destroy_t)(void*);
 int broadcast_grid(fxjps* h, int W, int H) {
     const int nd = (int)h->devs.size();
     if (nd == 1) return FXJPS_OK;
+    bool distinct = true;
+    for (int a = 0; a < nd; a++)
+        for (int b = a + 1; b < nd; b++)
+            if (h->devs[a].dev == h->devs[b].dev) distinct = false;
+    if (!distinct) {
+        // several contexts share a device (more shards than GPUs): RCCL wants one rank per device, so the grid is
+        // handed over by plain copies -- on-device for a context of the root's device, peer-to-peer otherwise
+        DevCtx& d0 = h->devs[0];
+        for (int r = 1; r < nd; r++) {
+            DevCtx& d = h->devs[r];
+            if (d.dev == d0.dev) {
+                HIPCHK(h, hipSetDevice(d.dev));
+                HIPCHK(h, hipMemcpyAsync(d.occ.p, d0.occ.p, (size_t)W * H, hipMemcpyDeviceToDevice, d.stream));
+            } else {
+                HIPCHK(h, hipMemcpyPeerAsync(d.occ.p, d.dev, d0.occ.p, d0.dev, (size_t)W * H, d.stream));
+            }
+        }
+        return FXJPS_OK;
+    }
     if (!h->rccl) {
         h->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h->rccl) h->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -679,7 +700,14 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
     int navail = 0;
     if (hipGetDeviceCount(&navail) != hipSuccess || navail <= 0)
         return fail(nullptr, FXJPS_E_NODEV, "no HIP device visible: the planner needs an MI355X (no CPU fallback)");
-    if (n_dev < 1 || n_dev > navail) return fail(nullptr, FXJPS_E_ARG, "n_dev=%d but %d device(s) visible", n_dev, navail);
+    // (a device id may appear more than once: the handle then keeps several independent contexts -- streams, maps,
+    // scratch, shards -- on that device; the grid reaches them by a device-to-device copy instead of the collective)
+    if (n_dev < 1 || n_dev > 64 || (!device_ids && n_dev > navail))
+        return fail(nullptr, FXJPS_E_ARG, "n_dev=%d but %d device(s) visible", n_dev, navail);
+    if (device_ids)
+        for (int r = 0; r < n_dev; r++)
+            if (device_ids[r] < 0 || device_ids[r] >= navail)
+                return fail(nullptr, FXJPS_E_ARG, "device id %d but %d device(s) visible", device_ids[r], navail);
     fxjps* h = new (std::nothrow) fxjps();
     if (!h) return fail(nullptr, FXJPS_E_NOMEM, "out of host memory");
     h->devs.resize(n_dev);
@@ -710,6 +738,10 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         }
         d.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         d.mem_total = prop.totalGlobalMem;
+    }
+    for (auto& a : h->devs) {
+        a.share = 0;
+        for (auto& b : h->devs) a.share += (a.dev == b.dev) ? 1 : 0;
     }
     *out = h;
     return FXJPS_OK;

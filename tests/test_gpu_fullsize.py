@@ -372,6 +372,34 @@ def test_two_process_sharded_planner_on_one_gpu(planner, tmp_path):
     assert_same(merged, planner.plan_batch(s, g, 2, 512))
 
 
+def test_in_library_sharding_on_one_gpu(planner):
+    """fxjps_create with the same device listed four times: four independent contexts (streams, maps, scratch,
+    contiguous shards, merged CSR) inside one handle -- everything of the in-library multi-device path except the
+    RCCL broadcast, which needs distinct GPUs."""
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(512, 448, 3, 0.20)
+    s, g = synth.synth_queries(occ, 3, 4001)
+    planner.set_grid_occ(occ)
+    ref = planner.plan_batch(s, g, 2, 1024)
+    with fx.Planner([0, 0, 0, 0]) as p4:
+        p4.set_grid_occ(occ)
+        assert_same(p4.plan_batch(s, g, 2, 1024), ref)
+        assert_same(p4.plan_batch(s[:3], g[:3], 2, 1024), planner.plan_batch(s[:3], g[:3], 2, 1024))  # fewer queries than shards
+        xy = np.array([[5, 5], [100, 7], [300, 300]], dtype=np.int32)
+        val = np.array([1, 1, 1], dtype=np.uint8)
+        p4.update_cells(xy, val)
+        planner.update_cells(xy, val)
+        assert_same(p4.plan_batch(s, g, 1, 1024), planner.plan_batch(s, g, 1, 1024))
+        p4.set_queries(s[:900], g[:900], 2, 1024)
+        planner.set_queries(s[:900], g[:900], 2, 1024)
+        for f in range(3):
+            xy = np.array([[40 + f, 41], [200, 9 + f]], dtype=np.int32)
+            val = np.array([f & 1, 1], dtype=np.uint8)
+            assert_same(p4.replan_frame(xy, val), planner.replan_frame(xy, val))
+        assert p4.timing()["reused"] > 0
+
+
 def test_in_library_multi_device_handle(planner):
     """fxjps_create(n_dev = 2): RCCL broadcast of the grid + contiguous shards inside the library (no torch)."""
     import fuxi_planner_amd as fx
