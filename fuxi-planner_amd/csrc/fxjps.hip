@@ -438,14 +438,14 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     HIPCHK(h, d.d_path.ensure((size_t)nq * max_len));
     HIPCHK(h, d.d_offsets.ensure((size_t)nq + 1));
     HIPCHK(h, d.d_next.ensure(4));
-    HIPCHK(h, d.d_counters.ensure(32));
+    HIPCHK(h, d.d_counters.ensure(64));
     HIPCHK(h, d.h_len.ensure((size_t)nq));
     HIPCHK(h, d.h_cost.ensure((size_t)nq));
     HIPCHK(h, d.h_offsets.ensure((size_t)nq + 1));
-    HIPCHK(h, d.h_counters.ensure(32));
+    HIPCHK(h, d.h_counters.ensure(64));
     HIPCHK(h, hipMemcpyAsync(d.d_starts.p, starts + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.d_goals.p, goals + 2 * d.q0, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 32 * sizeof(unsigned long long), d.stream));
+    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 64 * sizeof(unsigned long long), d.stream));
     if (getenv("FXJPS_QSTAT")) {  // diagnostics: per-query start / end time, pops, wavefront (tools/qstat.py)
         HIPCHK(h, d.d_qstat.ensure((size_t)nq * 4));
         HIPCHK(h, hipMemsetAsync(d.d_qstat.p, 0, (size_t)nq * 4 * sizeof(unsigned long long), d.stream));
@@ -529,7 +529,7 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(d.h_offsets.p, d.d_offsets.p, ((size_t)nq + 1) * sizeof(long long), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(h, hipMemcpyAsync(d.h_cost.p, d.d_cost.p, (size_t)nq * sizeof(double), hipMemcpyDeviceToHost, d.stream));
-    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
     if (d.mode != 0 && d.launches > 0) {  // the read sets of what ran (the rest of the buffer is unchanged)
         d.h_qread.resize((size_t)nq * 128);
         HIPCHK(h, hipMemcpyAsync(d.h_qread.data(), d.d_qread.p, (size_t)nq * 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
@@ -1256,7 +1256,7 @@ int fxjps_debug_counters(fxjps_t* h, unsigned long long* out32) {
     if (!h || !out32) return FXJPS_E_ARG;
     DevCtx& d = h->devs[0];
     if (!d.h_counters.p) return FXJPS_E_ARG;
-    memcpy(out32, d.h_counters.p, 32 * sizeof(unsigned long long));
+    memcpy(out32, d.h_counters.p, 64 * sizeof(unsigned long long));
     return FXJPS_OK;
 }
 
@@ -1274,7 +1274,7 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
     if (!h || !mismatches || rounds < 1 || rounds > (1 << 16)) return FXJPS_E_ARG;
     DevCtx& d = h->devs[0];
     HIPCHK(h, hipSetDevice(d.dev));
-    std::vector<uint64_t> in((size_t)rounds * 64), out((size_t)rounds * 4 + (size_t)rounds * 32);  // minima, then u32 ranks
+    std::vector<uint64_t> in((size_t)rounds * 64), out((size_t)rounds * 4 + (size_t)rounds * 64);  // minima, then u32 ranks (32-bit keys, 96-bit keys)
     uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
     for (size_t i = 0; i < in.size(); i++) {
         x ^= x << 13;
@@ -1312,6 +1312,27 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
             uint32_t c = 0;
             for (int m = 0; m < 64; m++) c += ((uint32_t)(in[(size_t)r * 64 + m] >> 7) < k) ? 1u : 0u;
             if (rk[l] != c) {
+                bad++;
+                break;
+            }
+        }
+        // wave_rank96: the same for three-dword keys compared as (hi : lo : x); few distinct values per dword, so that
+        // every dword decides some of the comparisons and many keys tie
+        const uint32_t* rk3 = reinterpret_cast<const uint32_t*>(out.data() + (size_t)rounds * 4 + (size_t)rounds * 32) + (size_t)r * 64;
+        auto k96 = [&](int l, uint32_t& hi, uint32_t& lo, uint32_t& x) {
+            const uint64_t v = in[(size_t)r * 64 + l];
+            hi = (uint32_t)(v >> 40) & 0x3u;
+            lo = (uint32_t)v & 0x7u;
+            x = (uint32_t)(v >> 9) & 0x3u;
+        };
+        for (int l = 0; l < 64; l++) {
+            uint32_t h, lo, x, oh, ol, ox, c = 0;
+            k96(l, h, lo, x);
+            for (int m = 0; m < 64; m++) {
+                k96(m, oh, ol, ox);
+                c += (oh < h || (oh == h && (ol < lo || (ol == lo && ox < x)))) ? 1u : 0u;
+            }
+            if (rk3[l] != c) {
                 bad++;
                 break;
             }

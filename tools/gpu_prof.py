@@ -25,7 +25,7 @@ for nq in nqs:
     for rep in range(2):
         t = time.time(); off, cells, cost, st = p.plan_batch(s, g, int(os.environ.get("FX_HC", "2")), 1024 if W == 1024 else 4096); dt = time.time() - t
     tm = p.timing()
-    c = (C.c_uint64 * 32)(); L.fxjps_debug_counters(p._h, c); c = list(c)
+    c = (C.c_uint64 * 64)(); L.fxjps_debug_counters(p._h, c); c = list(c)
     print("nq=%d wall %.3fs kernel %.1f ms -> %.0f plans/s | pops %d pushes %d refills %d slow %d retried %d nopath %d" % (
         nq, dt, tm["search_kernel_ms"], nq / dt, c[0], c[1], c[2], c[3], tm["retried"], int((st == 0).sum())), flush=True)
     if c[4]:
@@ -35,7 +35,8 @@ for nq in nqs:
     if c[4] and c[20]:
         print("   R refills: one per %.1f batches, %.1f entries each, %.2f aiming rounds each, exact sort in %.1f %%" % (c[4] / c[20], c[23] / c[20], c[21] / c[20], 100.0 * c[22] / c[20]), flush=True)
     if c[4]:
-        if c[29]: print("   R refill: %.0f cycles each (%d of them)" % (c[28] / c[29], c[29]), flush=True)
+        if c[29]: print("   R refill: %.0f cycles each (%d of them): read M + threshold %.0f, select + gather %.0f, sort %.0f, compaction %.0f" % (
+            c[28] / c[29], c[29], c[40] / c[29], c[41] / c[29], c[42] / c[29], (c[28] - c[40] - c[41] - c[42]) / c[29]), flush=True)
         if c[26]: print("   far refill passes %d, entries scanned per pass %.0f, passes per refill %.2f, cycles per pass %.0f" % (c[26], c[27] / c[26], c[26] / max(c[2], 1), c[30] / c[26]), flush=True)
     if c[4]:
         print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
