@@ -394,6 +394,8 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.far = d.far[pool].p;
     A.log2_buckets = c.log2_buckets;
     A.far_cap = c.far_cap;
+    A.near_max = 1280;  // near band of the far tier: re-banded beyond this many entries (FXJPS_NEAR_MAX: test aid)
+    if (const char* e = getenv("FXJPS_NEAR_MAX")) A.near_max = (uint32_t)std::max(1, atoi(e));
     A.next = d.d_next.p;
     A.wave_gen = d.wave_gen[pool].p;
     A.max_pops = 64ull * (unsigned long long)d.W * d.H + 4096ull;
