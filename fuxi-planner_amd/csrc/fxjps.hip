@@ -394,7 +394,8 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.far = d.far[pool].p;
     A.log2_buckets = c.log2_buckets;
     A.far_cap = c.far_cap;
-    A.near_max = 1280;  // near band of the far tier: re-banded beyond this many entries (FXJPS_NEAR_MAX: test aid)
+    A.near_max = 512;  // near band of the far tier: re-banded beyond this many entries (FXJPS_NEAR_MAX: test / measurement aid;
+                       // measured on c2 / c4 shard / c3: 256 .. 512 with 10 .. 16 refill widths per band is the plateau)
     if (const char* e = getenv("FXJPS_NEAR_MAX")) A.near_max = (uint32_t)std::max(1, atoi(e));
     A.next = d.d_next.p;
     A.wave_gen = d.wave_gen[pool].p;

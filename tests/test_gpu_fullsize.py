@@ -230,6 +230,27 @@ def test_scratch_overflow_retries_on_the_large_pool(planner, oracle):
     assert_same(planner.plan_batch(s, g, 2, 512), ref)
 
 
+def test_far_tier_rebanding(planner, oracle):
+    """The far tier of the open list keeps two bands (a refill scans the near one only).  With the near band limited
+    to 48 entries every far refill re-bands -- splits of the near band, hand-overs from the far band, refills clamped
+    at the band threshold -- on maps whose open lists are a few hundred entries; results as always."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(448, 384, 61, 0.20)
+    s, g = synth.synth_queries(occ, 61, 700)
+    with with_env(FXJPS_NEAR_MAX=48):
+        planner.set_grid_occ(occ)
+        for h in (2, 1):
+            res = planner.plan_batch(s, g, h, 1024)
+            assert planner.timing()["far_refills"] > 500 and planner.timing()["retried"] == 0
+            assert_same(res, oracle_csr(oracle, occ, s, g, h, 1024))
+    with with_env(FXJPS_NEAR_MAX=1, FXJPS_FAR_CAP=512):  # ... and with bands of 256 entries that overflow now and then
+        planner.set_grid_occ(occ)
+        res = planner.plan_batch(s, g, 2, 1024)
+        print("rebanding with a 512-entry far tier", planner.timing())
+        assert_same(res, oracle_csr(oracle, occ, s, g, 2, 1024))
+    planner.set_grid_occ(occ)
+
+
 def test_generation_wrap_and_table_wipe(planner, oracle):
     """8 resident wavefronts and 2 400 queries: 300 searches per wavefront, i.e. four wraps of the 6-bit generation
     tag with a table wipe each."""
