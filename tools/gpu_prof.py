@@ -40,6 +40,12 @@ for nq in nqs:
         if c[26]: print("   far refill passes %d, entries scanned per pass %.0f, passes per refill %.2f, cycles per pass %.0f" % (c[26], c[27] / c[26], c[26] / max(c[2], 1), c[30] / c[26]), flush=True)
     if c[4]:
         print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
+    if c[4] and c[33]:
+        print("   lanes in use %.1f / batch, nodes without lanes %.2f / batch, behind a shared bucket %.2f / batch, key-rule count ran in %.1f %% of the batches" % (
+            c[33] / c[4], c[34] / c[4], c[31] / c[4], 100.0 * c[32] / c[4]), flush=True)
+    if c[4] and c[35]:
+        print("   rays held back by the bucket detector %.2f / batch: %.1f %% share the bucket, %.1f %% the cell; batches cut %.1f %%, of those by a real one %.1f %%" % (
+            c[35] / c[4], 100.0 * c[36] / c[35], 100.0 * c[37] / c[35], 100.0 * c[39] / c[4], 100.0 * c[38] / max(c[39], 1)), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
