@@ -404,13 +404,6 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
     waves = std::min<uint32_t>(waves, c.nwaves);
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
-    {   // issue priorities for the head of the longest-first order (FXJPS_PRIO=a,b,c in eighths of the resident wavefronts: measurement aid)
-        int e3 = 1, e2 = 4, e1 = 8;
-        if (const char* e = getenv("FXJPS_PRIO")) sscanf(e, "%d,%d,%d", &e3, &e2, &e1);
-        A.prio3 = d_order ? (uint32_t)((uint64_t)waves * (uint32_t)std::max(e3, 0) / 8u) : 0u;
-        A.prio2 = d_order ? (uint32_t)((uint64_t)waves * (uint32_t)std::max(e2, 0) / 8u) : 0u;
-        A.prio1 = d_order ? (uint32_t)((uint64_t)waves * (uint32_t)std::max(e1, 0) / 8u) : 0u;
-    }
     const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));

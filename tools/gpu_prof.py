@@ -46,6 +46,10 @@ for nq in nqs:
     if c[4] and c[35]:
         print("   rays held back by the bucket detector %.2f / batch: %.1f %% share the bucket, %.1f %% the cell; batches cut %.1f %%, of those by a real one %.1f %%" % (
             c[35] / c[4], 100.0 * c[36] / c[35], 100.0 * c[37] / c[35], 100.0 * c[39] / c[4], 100.0 * c[38] / max(c[39], 1)), flush=True)
+    if c[4]:
+        print("   duplicate nodes %.3f / batch, batches with one %.2f %%" % (c[45] / c[4], 100.0 * c[46] / c[4]), flush=True)
+        print("   commit in detail, cycles / batch: stores + counts %.0f, classify %.0f, far append + R merge %.0f, M append %.0f" % (
+            c[10] / c[4], c[60] / c[4], c[61] / c[4], c[62] / c[4]), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
