@@ -44,8 +44,8 @@ for nq in nqs:
         print("   lanes in use %.1f / batch, nodes without lanes %.2f / batch, behind a shared bucket %.2f / batch, key-rule count ran in %.1f %% of the batches" % (
             c[33] / c[4], c[34] / c[4], c[31] / c[4], 100.0 * c[32] / c[4]), flush=True)
     if c[4] and c[35]:
-        print("   rays held back by the bucket detector %.2f / batch: %.1f %% share the bucket, %.1f %% the cell; batches cut %.1f %%, of those by a real one %.1f %%" % (
-            c[35] / c[4], 100.0 * c[36] / c[35], 100.0 * c[37] / c[35], 100.0 * c[39] / c[4], 100.0 * c[38] / max(c[39], 1)), flush=True)
+        print("   rays held back by the bucket detector %.3f / batch (in %.1f %% of the batches): %.1f %% really share a bucket, %.1f %% relaxed as the second of a pair; batches cut %.1f %%" % (
+            c[35] / c[4], 100.0 * c[39] / c[4], 100.0 * c[36] / c[35], 100.0 * c[37] / c[35], 100.0 * c[38] / c[4]), flush=True)
     if c[4]:
         print("   duplicate nodes %.3f / batch, batches with one %.2f %%" % (c[45] / c[4], 100.0 * c[46] / c[4]), flush=True)
         print("   commit in detail, cycles / batch: stores + counts %.0f, classify %.0f, far append + R merge %.0f, M append %.0f" % (
