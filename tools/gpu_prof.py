@@ -38,6 +38,9 @@ for nq in nqs:
         if c[29]: print("   R refill: %.0f cycles each (%d of them): read M + threshold %.0f, select + gather %.0f, sort %.0f, compaction %.0f" % (
             c[28] / c[29], c[29], c[40] / c[29], c[41] / c[29], c[42] / c[29], (c[28] - c[40] - c[41] - c[42]) / c[29]), flush=True)
         if c[26]: print("   far refill passes %d, entries scanned per pass %.0f, passes per refill %.2f, cycles per pass %.0f" % (c[26], c[27] / c[26], c[26] / max(c[2], 1), c[30] / c[26]), flush=True)
+    if c[26]:
+        print("   far tier: %d re-bandings down, %d up, %.0f entries gone through each; entries scanned per pop: refills %.2f, re-banding %.2f" % (
+            c[43], c[44], c[47] / max(c[43] + c[44], 1), c[27] / max(c[0], 1), c[47] / max(c[0], 1)), flush=True)
     if c[4]:
         print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
     if c[4] and c[33]:
