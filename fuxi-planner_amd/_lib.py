@@ -22,7 +22,7 @@ SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy
 class Timing(C.Structure):
     _fields_ = [("search_kernel_ms", C.c_double), ("total_ms", C.c_double), ("search_launches", C.c_int64),
                 ("retried", C.c_int64), ("pops", C.c_int64), ("pushes", C.c_int64), ("far_refills", C.c_int64),
-                ("slow_pops", C.c_int64), ("table_wipes", C.c_int64), ("reused", C.c_int64)]
+                ("slow_pops", C.c_int64), ("table_wipes", C.c_int64), ("reused", C.c_int64), ("table_direct", C.c_int64)]
 
 
 class FxjpsError(RuntimeError):

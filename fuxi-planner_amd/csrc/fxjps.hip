@@ -94,6 +94,7 @@ struct HBuf {  // grow-only pinned host buffer
 struct ScratchCfg {
     uint32_t nwaves = 0;
     uint32_t log2_buckets = 0;
+    uint32_t direct_ly = 0;  // > 0: the table is indexed by the cell (slot = x << direct_ly | y), see ensure_pool
     uint32_t far_cap = 0;
 };
 
@@ -314,6 +315,22 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
             l2e += shift;
         }
         l2e = std::min(std::max(l2e, 12u), 23u);
+        // A table with one slot per cell (slot = x << ly | y, both extents rounded up to powers of two) needs no
+        // hashing, no buckets and cannot fill up: a probe is one 16-byte entry instead of a 64-byte bucket searched for
+        // the cell.  Taken whenever a full set of wavefronts fits the same 40 % of the device with it (up to 2^20
+        // slots: 1024^2, where it is exactly as large as the hashed table was); larger grids keep the hashed table.
+        // FXJPS_DIRECT=0: measurement / test aid.
+        {
+            const uint32_t lx = std::max(ceil_log2((uint64_t)d.W), 1u), ly = std::max(ceil_log2((uint64_t)d.H), 1u);
+            const uint32_t ld = std::max(lx + ly, 12u);
+            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC / (uint64_t)d.share;
+            const uint64_t cap = (d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30)) / (uint64_t)d.share;
+            const bool allow = !(getenv("FXJPS_DIRECT") && atoi(getenv("FXJPS_DIRECT")) == 0) && !getenv("FXJPS_TABLE_LOG2");
+            if (allow && ld <= 23u && full * ((uint64_t)19 << ld) <= cap) {
+                l2e = ld;
+                c.direct_ly = ly;
+            }
+        }
         // test aids: force a small table / far tier so that the overflow -> large-pool retry paths run
         if (const char* e = getenv("FXJPS_TABLE_LOG2")) l2e = (uint32_t)std::min(std::max(atoi(e), 4), 23);
         c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
@@ -345,7 +362,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     if (maxw < (uint32_t)fx::WPB) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
     c.nwaves = std::max((uint32_t)fx::WPB, std::min((c.nwaves + WPBm) & ~WPBm, maxw));
     ScratchCfg& cur = d.cfg[pool];
-    const bool same = cur.log2_buckets == c.log2_buckets && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
+    const bool same = cur.log2_buckets == c.log2_buckets && cur.direct_ly == c.direct_ly && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
     if (same && d.pool_clean[pool]) return FXJPS_OK;
     if (!same) {
         // the old buffers die inside ensure(): forget the old configuration first, so that a failed allocation can
@@ -393,6 +410,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.tables = d.tables[pool].p;
     A.far = d.far[pool].p;
     A.log2_buckets = c.log2_buckets;
+    A.direct_ly = c.direct_ly;
     A.far_cap = c.far_cap;
     A.near_max = 512;  // near band of the far tier: re-banded beyond this many entries (FXJPS_NEAR_MAX: test / measurement aid;
                        // measured on c2 / c4 shard / c3: 256 .. 512 with 10 .. 16 refill widths per band is the plateau)
@@ -407,15 +425,14 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
-    if (track) {  // the instantiation that records each search's read set (fxjps_replan_frame)
-        if (hchoice == 1)
-            hipLaunchKernelGGL((fx::k_search<1, true>), grid, block, 0, d.stream, A);
-        else
-            hipLaunchKernelGGL((fx::k_search<2, true>), grid, block, 0, d.stream, A);
-    } else if (hchoice == 1) {
-        hipLaunchKernelGGL((fx::k_search<1, false>), grid, block, 0, d.stream, A);
-    } else {
-        hipLaunchKernelGGL((fx::k_search<2, false>), grid, block, 0, d.stream, A);
+    // instantiations: heuristic x read-set recording (fxjps_replan_frame) x table indexed by the cell
+    {
+        using KFn = void (*)(SearchArgs);
+        static const KFn kfn[2][2][2] = {{{fx::k_search<1, false, false>, fx::k_search<1, false, true>},
+                                          {fx::k_search<1, true, false>, fx::k_search<1, true, true>}},
+                                         {{fx::k_search<2, false, false>, fx::k_search<2, false, true>},
+                                          {fx::k_search<2, true, false>, fx::k_search<2, true, true>}}};
+        hipLaunchKernelGGL(kfn[hchoice == 1 ? 0 : 1][track ? 1 : 0][c.direct_ly > 0 ? 1 : 0], grid, block, 0, d.stream, A);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(d.ev1, d.stream));
@@ -596,6 +613,7 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     T.slow_pops = 0;
     T.table_wipes = 0;
     T.reused = 0;
+    T.table_direct = 0;
     for (auto& d : h->devs) {
         T.search_kernel_ms = std::max(T.search_kernel_ms, d.kernel_ms);
         T.search_launches += d.launches;
@@ -606,6 +624,7 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
             T.far_refills += (int64_t)d.h_counters.p[2];
             T.slow_pops += (int64_t)d.h_counters.p[3];
             T.table_wipes += (int64_t)d.h_counters.p[7];
+            if (d.cfg[0].direct_ly > 0) T.table_direct = 1;
         }
     }
     return FXJPS_OK;

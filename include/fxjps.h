@@ -188,6 +188,8 @@ typedef struct fxjps_timing {
     int64_t slow_pops;       /* pops taken straight from the global-memory tier (> 256 entries tied at the minimum key) */
     int64_t table_wipes;     /* visited-table wipes after a wavefront's generation counter wrapped (every 63 searches) */
     int64_t reused;          /* fxjps_replan_frame: stored results returned without a search (their read set was untouched) */
+    int64_t table_direct;    /* 1: the last batch ran on visited tables indexed by the cell (grids of up to 2^20 slots), 0: on
+                                hashed tables of 4-slot buckets (larger grids; FXJPS_DIRECT=0) */
 } fxjps_timing_t;
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
 

@@ -230,6 +230,29 @@ def test_scratch_overflow_retries_on_the_large_pool(planner, oracle):
     assert_same(planner.plan_batch(s, g, 2, 512), ref)
 
 
+def test_hashed_and_cell_indexed_tables(planner, oracle):
+    """Grids of up to 2^20 slots get visited tables indexed by the cell (one 16-byte entry per probe); larger ones --
+    config 3 -- hashed tables of 4-slot buckets.  FXJPS_DIRECT=0 runs the hashed tables (buckets, linear probing, the
+    shared-bucket rule) on small maps too: the same bytes either way, both heuristics."""
+    from fuxi_planner_amd import synth
+    for W, H, seed, p, nq, mpl in ((1024, 1024, 1, 0.20, 2500, 1024), (333, 517, 7, 0.25, 900, 1024), (200, 160, 9, 0.10, 500, 512),
+                                    (1100, 900, 4, 0.20, 600, 1024)):
+        occ = synth.synth_grid(W, H, seed, p)
+        s, g = synth.synth_queries(occ, seed, nq)
+        want = {h: oracle_csr(oracle, occ, s, g, h, mpl) for h in (2, 1)}
+        planner.set_grid_occ(occ)
+        for h in (2, 1):
+            assert_same(planner.plan_batch(s, g, h, mpl), want[h])
+        direct = planner.timing()["table_direct"]
+        assert direct == (1 if (W - 1).bit_length() + (H - 1).bit_length() <= 20 else 0), (W, H, direct)  # (x << ly | y in 2^20 slots)
+        with with_env(FXJPS_DIRECT=0):
+            planner.set_grid_occ(occ)  # new scratch configuration
+            for h in (2, 1):
+                assert_same(planner.plan_batch(s, g, h, mpl), want[h])
+            assert planner.timing()["table_direct"] == 0
+    planner.set_grid_occ(occ)
+
+
 def test_far_tier_rebanding(planner, oracle):
     """The far tier of the open list keeps two bands (a refill scans the near one only).  With the near band limited
     to 48 entries every far refill re-bands -- splits of the near band, hand-overs from the far band, refills clamped
