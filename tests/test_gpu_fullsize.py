@@ -253,6 +253,33 @@ def test_hashed_and_cell_indexed_tables(planner, oracle):
     planner.set_grid_occ(occ)
 
 
+def test_far_tier_in_bands(planner, oracle):
+    """On large grids (config 3) the far band of the open list is a set of f bands that a refill takes whole.
+    FXJPS_BANDED=1 runs it on maps of config-2 size too (hashed tables: FXJPS_DIRECT=0), where thousands of refills set
+    the bands up, use them up, deal the last region out again and hand oversized bands to the scanning path; with a
+    far tier of 24 576 entries (band regions of 146) regions overflow and the queries are re-run on the large pool."""
+    from fuxi_planner_amd import synth
+    cases = (((1024, 1024, 1, 0.20, 1500), {}), ((1100, 900, 4, 0.20, 600), {}), ((900, 1000, 12, 0.05, 400), {}),
+             ((1024, 1024, 1, 0.20, 600), {"FXJPS_FAR_CAP": 24576}))
+    for (W, H, seed, p, nq), extra in cases:
+        occ = synth.synth_grid(W, H, seed, p)
+        s, g = synth.synth_queries(occ, seed, nq)
+        want = oracle_csr(oracle, occ, s, g, 2, 2048)
+        with with_env(FXJPS_BANDED=1, FXJPS_DIRECT=0, **extra):
+            planner.set_grid_occ(occ)  # new scratch configuration
+            res = planner.plan_batch(s, g, 2, 2048)
+            tm = planner.timing()
+            print("bands", (W, H, p), extra, tm)
+            assert tm["far_refills"] > 1000 and tm["table_direct"] == 0
+            if extra:
+                assert tm["retried"] > 0
+            assert_same(res, want)
+        with with_env(FXJPS_BANDED=0, FXJPS_DIRECT=0):
+            planner.set_grid_occ(occ)
+            assert_same(planner.plan_batch(s, g, 2, 2048), want)
+    planner.set_grid_occ(occ)
+
+
 def test_far_tier_rebanding(planner, oracle):
     """The far tier of the open list keeps two bands (a refill scans the near one only).  With the near band limited
     to 48 entries every far refill re-bands -- splits of the near band, hand-overs from the far band, refills clamped
