@@ -147,11 +147,13 @@ def main():
     status = None
     retried = 0
     reused = 0
+    direct = 0
     for i in range(a.steps):
         status, tm = step(a.warmup + i)
         kernel_ms.append(tm["search_kernel_ms"])
         retried += tm["retried"]
         reused += tm["reused"]
+        direct = tm.get("table_direct", 0)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -204,9 +206,11 @@ def main():
                        "parallelism": ("one process, fxjps_create(n_dev=%d)" % n_units) if a.inlib else "queries sharded x%d, one process per GPU" % n_units},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                         "kernel": "fx::k_search<%d>" % hchoice, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
+                         # (the instantiation rocprofv3 lists: heuristic, read-set recording, table indexed by the cell)
+                         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and a.workload != "c5") else "false", "true" if direct else "false"),
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
                          "algorithmic_bytes_source": wl.get("algorithmic_bytes_source", "oracle literal mode, all queries (tools/algo_bytes.py)"),
-                         "note": "latency-bound graph search (DESIGN.md section 4); traffic: " + tnote},
+                         "note": "graph search bound by scattered-request rate and instruction issue, not by bytes (DESIGN.md section 4); traffic: " + tnote},
         }
         if streaming:
             out["config"].update({"frames_per_s": a.steps / elapsed, "target_frames_per_s": 60,
