@@ -253,6 +253,29 @@ def test_hashed_and_cell_indexed_tables(planner, oracle):
     planner.set_grid_occ(occ)
 
 
+def test_grid_of_6144_with_2_to_the_27_slot_tables(planner, oracle):
+    """Above 5 793 cells a side the tables of the large pool have 2^27 slots: every 27-bit value is a valid parent slot
+    (the walk back ends at the start cell, not at a sentinel).  Eight queries on 6144 x 6144, once on the regular pool
+    and once with a tiny first table so that they are re-run on the large one; paths of thousands of jump points."""
+    from fuxi_planner_amd import synth
+    W = H = 6144
+    occ = synth.synth_grid(W, H, 5, 0.20)
+    s, g = synth.synth_queries(occ, 5, 8)
+    want = oracle_csr(oracle, occ, s, g, 2, 8192)
+    planner.set_grid_occ(occ)
+    res = planner.plan_batch(s, g, 2, 8192)
+    assert planner.timing()["table_direct"] == 0
+    assert_same(res, want)
+    with with_env(FXJPS_TABLE_LOG2=14):
+        planner.set_grid_occ(occ)  # new scratch configuration
+        res = planner.plan_batch(s, g, 2, 8192)
+        print("6144^2, large pool:", planner.timing())
+        assert planner.timing()["retried"] > 0
+        assert_same(res, want)
+    occ = synth.synth_grid(64, 64, 1, 0.2)
+    planner.set_grid_occ(occ)  # (gives the large buffers back)
+
+
 def test_far_tier_in_bands(planner, oracle):
     """On large grids (config 3) the far band of the open list is a set of f bands that a refill takes whole.
     FXJPS_BANDED=1 runs it on maps of config-2 size too (hashed tables: FXJPS_DIRECT=0), where thousands of refills set
