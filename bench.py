@@ -12,7 +12,9 @@ generator fuxi-planner_amd/synth.py):
     c4       BASELINE config 4 itself: 1 000 000 queries split over the N ranks (strong scaling)
     c5       BASELINE config 5, streaming replan: a step is one frame = toggle 10 % of the cells + rebuild the maps +
              plan the 1 000 persistent queries (SURVEY 8d toggle stream); c5low = the same with 0.1 % toggles;
-             c5local = one 64 x 64 window re-observed per frame (the exact-reuse case of fxjps_replan_frame)
+             c5local = one 64 x 64 window re-observed per frame (the exact-reuse case of fxjps_replan_frame);
+             c5pipe = config 5 with eight frames in flight (fuxi_planner_amd.replan.FramePipeline: eight planner handles
+             on the GPU take the frames in turn): the sustained frame rate, `--steps 32 --warmup 8` for a steady state
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
@@ -49,13 +51,17 @@ def kernel_src_sha16():
 
 
 def main():
+    # (c5pipe: one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run
+    # one after the other; read by the HIP runtime when it initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5pipe"])
     ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe: planner handles taking the frames in turn (0: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
     a = ap.parse_args()
 
@@ -129,7 +135,15 @@ def main():
             else:
                 dist.barrier()
 
-    if streaming:
+    pipe = None
+    if streaming and wl.get("frames_in_flight"):
+        if world > 1 or a.inlib:
+            raise SystemExit("c5pipe is a single-GPU workload")
+        if a.frames_in_flight > 0:
+            wl["frames_in_flight"] = a.frames_in_flight
+        from fuxi_planner_amd.replan import FramePipeline
+        pipe = FramePipeline(dev_index, int(wl["frames_in_flight"]), occ, starts, goals, hchoice, mpl)
+    elif streaming:
         planner.set_queries(starts, goals, hchoice, mpl)
 
     def step(i):
@@ -139,23 +153,46 @@ def main():
             off, cells, cost, status = planner.plan_batch(starts, goals, hchoice, mpl)  # blocking: results are in host memory
         return status, planner.timing()
 
-    for i in range(a.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
     kernel_ms = []
     status = None
     retried = 0
     reused = 0
     direct = 0
-    for i in range(a.steps):
-        status, tm = step(a.warmup + i)
-        kernel_ms.append(tm["search_kernel_ms"])
-        retried += tm["retried"]
-        reused += tm["reused"]
-        direct = tm.get("table_direct", 0)
-    sync()
-    elapsed = time.perf_counter() - t0
+    frame_latency_ms = None
+    if pipe is not None:  # frames in flight: submit them all, the pipeline hands each to the next free handle
+        for f in [pipe.submit(*frames[i]) for i in range(a.warmup)]:
+            f.result()
+        t0 = time.perf_counter()
+        t_sub, t_done = [], {}
+        futs = []
+        for i in range(a.steps):
+            t_sub.append(time.perf_counter())  # (submit blocks while the handle whose turn it is still plans)
+            f = pipe.submit(*frames[a.warmup + i])
+            f.add_done_callback(lambda _f, _i=i: t_done.__setitem__(_i, time.perf_counter()))
+            futs.append(f)
+        res = [f.result() for f in futs]
+        elapsed = time.perf_counter() - t0
+        if any((r[3] < 0).any() for r in res):
+            raise SystemExit("bench: queries failed")
+        status = res[-1][3]  # (the last frame's: the CPU baseline below plans on that frame's grid)
+        direct = 1
+        kernel_ms = [elapsed / a.steps * 1e3]  # (the launches of the frames overlap: the frame period stands in)
+        time.sleep(0.01)
+        frame_latency_ms = float(np.mean([(t_done[i] - t_sub[i]) * 1e3 for i in range(a.steps) if i in t_done]))
+        pipe.close()
+    else:
+        for i in range(a.warmup):
+            step(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            status, tm = step(a.warmup + i)
+            kernel_ms.append(tm["search_kernel_ms"])
+            retried += tm["retried"]
+            reused += tm["reused"]
+            direct = tm.get("table_direct", 0)
+        sync()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda:%d" % dev_index)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,7 +244,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                          # (the instantiation rocprofv3 lists: heuristic, read-set recording, table indexed by the cell)
-                         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and a.workload != "c5") else "false", "true" if direct else "false"),
+                         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and a.workload not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
                          "algorithmic_bytes_source": wl.get("algorithmic_bytes_source", "oracle literal mode, all queries (tools/algo_bytes.py)"),
                          "note": "graph search bound by scattered-request rate and instruction issue, not by bytes (DESIGN.md section 4); traffic: " + tnote},
@@ -216,11 +253,15 @@ def main():
             out["config"].update({"frames_per_s": a.steps / elapsed, "target_frames_per_s": 60,
                                   "cells_sent_per_frame": int(len(frames[0][1])),
                                   "results_reused_per_frame": reused / a.steps})
+            if pipe is not None:
+                out["config"].update({"frames_in_flight": int(wl["frames_in_flight"]), "frame_latency_ms": frame_latency_ms,
+                                      "parallelism": "%d planner handles on one GPU take the frames in turn" % int(wl["frames_in_flight"])})
+                out["roofline"]["note"] = "frames overlap: kernel_ms is the frame period; " + out["roofline"]["note"]
         if world == 1 and not a.inlib and not a.no_cpu_baseline:
             from oracle import oracle  # checker used as the CPU baseline ("port"), never by the planner
             ns = min(a.cpu_sample or wl.get("cpu_sample", nq), n_local)
             cores = min(os.cpu_count() or 1, 256)
-            g_now = planner.get_grid() if streaming else occ
+            g_now = g if pipe is not None else (planner.get_grid() if streaming else occ)
             tc = time.perf_counter()
             _, ol, _, _ = oracle.plan_batch(g_now, starts[:ns], goals[:ns], hchoice, literal=False, max_len=mpl, nthreads=min(cores, wl.get("cpu_threads", cores)))
             dt = time.perf_counter() - tc

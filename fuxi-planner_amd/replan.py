@@ -11,6 +11,7 @@ vehicle whose last search happened at x == 0.0 exactly always searches again (ke
         throttle.mark(planner.parse_local_position(planner.pos))      # the position is read again after the search
 """
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -33,3 +34,66 @@ class ReplanThrottle(object):
         """ccst:479-480."""
         self.last_pos = np.asarray(pos, dtype=np.float64).copy()
         self.last_time = self.clock()
+
+
+class FramePipeline(object):
+    """Streaming replan with several frames in flight (BASELINE config 5: a 60 Hz *rate*).
+
+    One frame -- cell updates, map rebuild, search of the persistent queries -- takes as long as its longest query:
+    73 ms for 1 000 queries at 1024^2, during most of which the chip is nearly idle.  The frames do not depend on each
+    other's results, only on the grid, so K planner handles on one device (own grid copy, own scratch, own stream) take
+    the frames in turn: handle f % K applies the updates of the frames since its last turn, in order, and plans frame f
+    while the K - 1 frames before it are still being searched.  Every frame's result is what fxjps_replan_frame returns
+    for that frame (same library calls, same kernels); the latency of a frame stays what it was, the rate is K times
+    higher until the chip is full.
+
+        pipe = FramePipeline(0, 6, occ, starts, goals)
+        futures = [pipe.submit(xy, val) for xy, val in frames]      # returns at once while a handle is free
+        for f in futures: offsets, cells, cost, status = f.result()
+    """
+
+    def __init__(self, device, k, occ, starts, goals, hchoice=2, max_path_len=None):
+        from .planner import Planner
+        self.k = int(k)
+        self.planners = [Planner([device]) for _ in range(self.k)]
+        for p in self.planners:
+            p.set_grid_occ(occ)
+            p.set_queries(starts, goals, hchoice, max_path_len)
+        self._backlog = [[] for _ in range(self.k)]  # updates a handle has not applied yet, oldest first
+        self._busy = [None] * self.k
+        self._pool = ThreadPoolExecutor(max_workers=self.k)
+        self._n = 0
+
+    def _run(self, j, updates):
+        p = self.planners[j]
+        for xy, val in updates[:-1]:  # the frames the other handles planned: the grid follows them
+            p.update_cells(xy, val)
+        return p.replan_frame(*updates[-1])
+
+    def submit(self, xy, val):
+        """Queue one frame.  Blocks only while the handle whose turn it is still plans its previous frame."""
+        xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
+        for b in self._backlog:
+            b.append((xy, val))
+        j = self._n % self.k
+        self._n += 1
+        if self._busy[j] is not None:
+            self._busy[j].result()
+        updates, self._backlog[j] = self._backlog[j], []
+        self._busy[j] = self._pool.submit(self._run, j, updates)
+        return self._busy[j]
+
+    def close(self):
+        for f in self._busy:
+            if f is not None:
+                f.result()
+        self._pool.shutdown(wait=True)
+        for p in self.planners:
+            p.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

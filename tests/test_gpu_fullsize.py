@@ -253,6 +253,30 @@ def test_hashed_and_cell_indexed_tables(planner, oracle):
     planner.set_grid_occ(occ)
 
 
+def test_frames_in_flight(oracle):
+    """FramePipeline: three planner handles on the GPU take the frames of a toggle stream in turn, each applying the
+    updates of the frames the others planned.  Every frame's result is the oracle's answer on that frame's grid."""
+    from fuxi_planner_amd import synth
+    from fuxi_planner_amd.replan import FramePipeline
+    W, H, nq, nframes = 384, 320, 300, 10
+    occ = synth.synth_grid(W, H, 31, 0.20)
+    s, g = synth.synth_queries(occ, 31, nq)
+    keep = np.zeros((W, H), dtype=bool)
+    keep[s[:, 0], s[:, 1]] = True
+    keep[g[:, 0], g[:, 1]] = True
+    grid = occ.copy()
+    frames, want = [], []
+    for fr in range(nframes):
+        xy, val = synth.synth_toggles(grid, keep, fr, 0.05, 77)
+        synth.apply_toggles(grid, xy, val)
+        frames.append((xy, val))
+        want.append(oracle_csr(oracle, grid, s, g, 2, 1024))
+    with FramePipeline(0, 3, occ, s, g, 2, 1024) as pipe:
+        futs = [pipe.submit(xy, val) for xy, val in frames]
+        for fr, f in enumerate(futs):
+            assert_same(f.result(), want[fr])
+
+
 def test_grid_of_6144_with_2_to_the_27_slot_tables(planner, oracle):
     """Above 5 793 cells a side the tables of the large pool have 2^27 slots: every 27-bit value is a valid parent slot
     (the walk back ends at the start cell, not at a sentinel).  Eight queries on 6144 x 6144, once on the regular pool

@@ -40,6 +40,7 @@ WORKLOADS = {
                     describe="config 5 with local churn (the ROS node's ticks: the map changes where the vehicle looks): per frame one 64x64 "
                              "window, moving with the frame index, is re-observed (all its cells sent, fresh 20% values), 1000 persistent queries"),
 }
+PIPE_FRAMES = 8  # c5pipe: config 5 with this many frames in flight (same frames, same counts: derived from c5)
 NT = min(os.cpu_count() or 8, 256)
 
 
@@ -94,6 +95,12 @@ def main():
             r4.update(algorithmic_bytes=8 * rec["algorithmic_bytes"], bytes_per_query=rec["bytes_per_query"],
                       algorithmic_bytes_source="8 x the literal count of the first 125000 queries (c4shard)")
             out["c4"] = r4
+        if name == "c5":  # the same frames with several of them in flight (bench.py --workload c5pipe)
+            rp = dict(rec, frames_in_flight=PIPE_FRAMES)
+            rp["describe"] = rec["describe"].replace("BASELINE config 5, streaming replan:",
+                "BASELINE config 5, streaming replan with %d frames in flight (%d planner handles on the GPU take the frames in "
+                "turn; every frame is the same fxjps_replan_frame call):" % (PIPE_FRAMES, PIPE_FRAMES))
+            out["c5pipe"] = rp
         with open(OUT, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
 
