@@ -416,6 +416,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     // scattered store per push instead of an append at a rank).  FXJPS_BANDED=0/1: measurement / test aid.
     A.banded = (uint64_t)d.W * (uint64_t)d.H >= (1ull << 22) ? 1u : 0u;
     if (const char* e = getenv("FXJPS_BANDED")) A.banded = atoi(e) != 0 ? 1u : 0u;
+    if (pool != 0) A.banded = 0u;  // the large pool is the last resort: its far tier has no regions that could fill up
     A.far_cap = c.far_cap;
     A.near_max = 512;  // near band of the far tier: re-banded beyond this many entries (FXJPS_NEAR_MAX: test / measurement aid;
                        // measured on c2 / c4 shard / c3: 256 .. 512 with 10 .. 16 refill widths per band is the plateau)
