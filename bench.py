@@ -51,9 +51,6 @@ def kernel_src_sha16():
 
 
 def main():
-    # (c5pipe: one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run
-    # one after the other; read by the HIP runtime when it initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -64,6 +61,10 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe: planner handles taking the frames in turn (0: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
     a = ap.parse_args()
+    if a.workload == "c5pipe":
+        # one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run one
+        # after the other; read by the HIP runtime when it initialises (nothing has touched the GPU yet)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
