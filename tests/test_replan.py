@@ -38,3 +38,69 @@ def test_mark_then_due():
     now[0] = 10.32
     assert t.due((0.0, 5.0, 1.0))                 # the reference's "x == 0 means never searched"
     assert isinstance(t.last_pos, np.ndarray)
+
+
+def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
+    """FramePipeline (host logic, no GPU): frame f goes to handle f % K, which first applies the updates of the frames
+    the other handles planned, oldest first -- so that the grid a frame is planned on is the grid after ITS update."""
+    import threading
+    import fuxi_planner_amd.planner as planner_mod
+    from fuxi_planner_amd.replan import FramePipeline
+
+    class FakePlanner(object):
+        made = []
+
+        def __init__(self, devices):
+            self.grid = None
+            self.calls = []
+            self.closed = False
+            self.lock = threading.Lock()
+            FakePlanner.made.append(self)
+
+        def set_grid_occ(self, occ):
+            self.grid = occ.copy()
+
+        def set_queries(self, starts, goals, hchoice, max_path_len):
+            self.nq = len(starts)
+
+        def update_cells(self, xy, val):
+            assert self.lock.acquire(blocking=False), "a handle is used by one thread at a time"
+            self.grid[xy[:, 0], xy[:, 1]] = val
+            self.calls.append("u")
+            self.lock.release()
+
+        def replan_frame(self, xy, val):
+            assert self.lock.acquire(blocking=False), "a handle is used by one thread at a time"
+            self.grid[xy[:, 0], xy[:, 1]] = val
+            self.calls.append("r")
+            out = self.grid.copy()
+            self.lock.release()
+            return out
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(planner_mod, "Planner", FakePlanner)
+    rng = np.random.default_rng(3)
+    occ = (rng.random((12, 9)) < 0.3).astype(np.uint8)
+    frames, want, g = [], [], occ.copy()
+    for fr in range(17):
+        n = int(rng.integers(0, 20))
+        xy = np.stack([rng.integers(0, 12, n), rng.integers(0, 9, n)], 1).astype(np.int32)
+        xy = np.unique(xy, axis=0).astype(np.int32).reshape(-1, 2)  # (one update per cell within a frame)
+        val = rng.integers(0, 2, len(xy)).astype(np.uint8)
+        g[xy[:, 0], xy[:, 1]] = val
+        frames.append((xy, val))
+        want.append(g.copy())
+    for k in (1, 3, 5):
+        FakePlanner.made = []
+        with FramePipeline(0, k, occ, np.zeros((4, 2), np.int32), np.ones((4, 2), np.int32)) as pipe:
+            futs = [pipe.submit(xy, val) for xy, val in frames]
+            got = [f.result() for f in futs]
+        assert len(FakePlanner.made) == k and all(p.closed for p in FakePlanner.made)
+        for fr in range(len(frames)):
+            assert np.array_equal(got[fr], want[fr]), (k, fr)
+        # handle j planned frames j, j + k, ...: before each of them the k - 1 updates of the others (j for the first)
+        for j, p in enumerate(FakePlanner.made):
+            assert "".join(p.calls).startswith("u" * j + "r")
+            assert p.calls.count("r") == len(range(j, len(frames), k))
