@@ -14,7 +14,7 @@ BACKEND_HIP = 1
 
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
-           "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
+           "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
            "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_debug_read_nbmask",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst")
 
@@ -90,6 +90,8 @@ def load():
     L.fxjps_get_grid.argtypes = [vp, p_u8, p_i32, p_i32]
     L.fxjps_update_cells.restype = C.c_int
     L.fxjps_update_cells.argtypes = [vp, p_i32, p_u8, C.c_int64]
+    L.fxjps_update_cells_deferred.restype = C.c_int
+    L.fxjps_update_cells_deferred.argtypes = [vp, p_i32, p_u8, C.c_int64]
     L.fxjps_set_queries.restype = C.c_int
     L.fxjps_set_queries.argtypes = [vp, p_i32, p_i32, C.c_int64, C.c_int32, C.c_int32]
     L.fxjps_replan_frame.restype = C.c_int

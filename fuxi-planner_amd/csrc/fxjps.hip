@@ -148,6 +148,7 @@ struct fxjps {
     std::vector<DevCtx> devs;
     std::string err;
     bool have_grid = false;
+    bool maps_stale = false;  // cell updates were applied without rebuilding the derived maps (fxjps_update_cells_deferred)
     fxjps_timing_t timing{};
     int64_t last_nq = 0;
     // persistent query set of the streaming-replan entry points (fxjps_set_queries / fxjps_replan_frame)
@@ -579,6 +580,8 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     return FXJPS_OK;
 }
 
+int update_cells_async(fxjps* h, const int32_t* xy, const uint8_t* val, int64_t n, bool derive);  // (below, with the streaming entry points)
+
 int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq, int hchoice, int max_len, int mode = 0) {
     if (!h) return FXJPS_E_ARG;
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_plan_batch before fxjps_set_grid");
@@ -587,6 +590,10 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
         return fail(h, FXJPS_E_ARG, "hchoice must be 1 or 2 (the reference raises TypeError, jps1.py:188)");
     if (max_len < 1 || max_len > (1 << 20)) return fail(h, FXJPS_E_ARG, "max_path_len out of range");
     if (nq > 0x7FFFFFF0ll) return fail(h, FXJPS_E_ARG, "too many queries in one batch");
+    if (h->maps_stale) {  // deferred cell updates: the maps are rebuilt once, in front of the search
+        int rc = update_cells_async(h, nullptr, nullptr, 0, true);
+        if (rc) return rc;
+    }
     const int nd = (int)h->devs.size();
     for (int r = 0; r < nd; r++) {  // contiguous shards: SURVEY 8(e)
         h->devs[r].q0 = nq * r / nd;
@@ -1061,23 +1068,30 @@ int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* ou
 
 namespace {
 // Queue the cell updates and the rebuild of the derived maps on every device's stream (no host wait).
-int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
+int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n, bool derive) {
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "cell update before fxjps_set_grid");
     if (n < 0 || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
-    if (n == 0) return FXJPS_OK;
+    if (n == 0 && !(derive && h->maps_stale)) return FXJPS_OK;
     // every device applies the same (small) update list; cheaper than re-broadcasting the grid
     for (auto& d : h->devs) {
         HIPCHK(h, hipSetDevice(d.dev));
-        HIPCHK(h, d.d_upd_xy.ensure((size_t)n * 2));
-        HIPCHK(h, d.d_upd_val.ensure((size_t)n));
-        HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-        HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, val, (size_t)n, hipMemcpyHostToDevice, d.stream));
-        hipLaunchKernelGGL(fx::k_update_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.occ.p,
-                           d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p, (long long)n);
-        HIPCHK(h, hipGetLastError());
-        int rc = derive_maps(h, d);
-        if (rc) return rc;
+        if (n > 0) {
+            HIPCHK(h, d.d_upd_xy.ensure((size_t)n * 2));
+            HIPCHK(h, d.d_upd_val.ensure((size_t)n));
+            HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+            HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, val, (size_t)n, hipMemcpyHostToDevice, d.stream));
+        }
+        if (n > 0) {
+            hipLaunchKernelGGL(fx::k_update_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.occ.p,
+                               d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p, (long long)n);
+            HIPCHK(h, hipGetLastError());
+        }
+        if (derive) {
+            int rc = derive_maps(h, d);
+            if (rc) return rc;
+        }
     }
+    h->maps_stale = !derive;
     return FXJPS_OK;
 }
 
@@ -1111,13 +1125,19 @@ int emit_csr(fxjps_t* h, int64_t nq, int64_t* out_offsets, int32_t* out_cells_xy
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
     if (!h) return FXJPS_E_ARG;
     h->q_results_valid = false;  // the grid changes behind the stored results
-    int rc = update_cells_async(h, xy, val, n);
+    int rc = update_cells_async(h, xy, val, n, true);
     if (rc) return rc;
     for (auto& d : h->devs) {
         HIPCHK(h, hipSetDevice(d.dev));
         HIPCHK(h, hipStreamSynchronize(d.stream));
     }
     return FXJPS_OK;
+}
+
+int fxjps_update_cells_deferred(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n) {
+    if (!h) return FXJPS_E_ARG;
+    h->q_results_valid = false;  // the grid changes behind the stored results
+    return update_cells_async(h, xy, val, n, false);  // queued; the next planning call (or fxjps_update_cells) rebuilds the maps
 }
 
 int fxjps_set_queries(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_xy, int64_t nq, int32_t hchoice,
@@ -1189,7 +1209,7 @@ int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     }
     // the frame's map update is queued in front of the search on the same streams: the first host wait of the frame
     // is the one for the search results
-    int rc = update_cells_async(h, xy, val, n);
+    int rc = update_cells_async(h, xy, val, n, true);
     if (rc) return rc;
     rc = plan_core(h, h->q_starts.data(), h->q_goals.data(), nq, h->q_hchoice, h->q_max_len, mode);
     if (rc) return rc;

@@ -156,12 +156,15 @@ class Planner(object):
         self._chk(self._L.fxjps_snapshot_image(self._h, _lib.ptr(out, C.c_uint8), int(channels), None, None))
         return out
 
-    def update_cells(self, xy, val):
+    def update_cells(self, xy, val, rebuild=True):
+        """Set cells of the resident grid.  rebuild=False: the derived maps are rebuilt by the next planning call (or
+        the next update with rebuild=True) instead of now -- for several updates in a row."""
         xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
         val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
         if len(val) != len(xy):
             raise ValueError("xy and val lengths differ")
-        self._chk(self._L.fxjps_update_cells(self._h, _lib.ptr(xy, C.c_int32), _lib.ptr(val, C.c_uint8), len(val)))
+        fn = self._L.fxjps_update_cells if rebuild else self._L.fxjps_update_cells_deferred
+        self._chk(fn(self._h, _lib.ptr(xy, C.c_int32), _lib.ptr(val, C.c_uint8), len(val)))
 
     # -- planning
     def default_max_path_len(self):

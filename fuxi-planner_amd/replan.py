@@ -66,8 +66,8 @@ class FramePipeline(object):
 
     def _run(self, j, updates):
         p = self.planners[j]
-        for xy, val in updates[:-1]:  # the frames the other handles planned: the grid follows them
-            p.update_cells(xy, val)
+        for xy, val in updates[:-1]:  # the frames the other handles planned: the grid follows them (the maps are
+            p.update_cells(xy, val, rebuild=False)  # rebuilt once, by the frame's own call)
         return p.replan_frame(*updates[-1])
 
     def submit(self, xy, val):

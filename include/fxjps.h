@@ -131,6 +131,13 @@ int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* ou
  * obstacle) on the resident grid and rebuild the derived maps. */
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
 
+/* fxjps_update_cells without the rebuild of the derived maps: the updates are applied to the resident grid (calls are
+ * applied in order; one update per cell within a call) and the maps are rebuilt once by the next fxjps_update_cells,
+ * fxjps_plan_batch* or fxjps_replan_frame.  For hosts that hand a handle several frames' updates before it plans
+ * again (fuxi_planner_amd.replan.FramePipeline; scripts/global_planner_st.py:15-25 delivers one map message per
+ * callback, the node plans once per tick). */
+int fxjps_update_cells_deferred(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
+
 /* Streaming replan with a persistent query set (SURVEY.md 8f, row N4 / BASELINE config 5: the node replans the same
  * goals tick after tick, scripts/global_planner_ccst.py:476-480).  fxjps_set_queries stores nq (start, goal) pairs,
  * hchoice and max_path_len in the handle (copied).  fxjps_replan_frame applies one frame of cell updates (as

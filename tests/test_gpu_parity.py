@@ -242,6 +242,47 @@ def test_update_cells_equals_fresh_upload(planner, oracle):
     gpu_vs_oracle(planner, oracle, occ2, s, g, 2)
 
 
+def test_deferred_cell_updates(planner, oracle):
+    """fxjps_update_cells_deferred: three updates in a row without rebuilding the maps (a cell may change in each of
+    them: the calls are applied in order), then a plan -- which rebuilds them once -- equals a fresh upload; so does a
+    streaming frame and a rebuilding update behind deferred ones."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(200, 160, 8, 0.20)
+    rng = np.random.default_rng(6)
+    s, g = synth.synth_queries(occ, 9, 300)
+
+    def some_updates(grid, k):
+        out = []
+        for _ in range(k):
+            idx = rng.choice(200 * 160, 2500, replace=False)
+            xy = np.stack([idx // 160, idx % 160], 1).astype(np.int32)
+            val = rng.integers(0, 2, len(xy)).astype(np.uint8)
+            grid[xy[:, 0], xy[:, 1]] = val
+            out.append((xy, val))
+        return out
+
+    planner.set_grid_occ(occ)
+    cur = occ.copy()
+    for xy, val in some_updates(cur, 3):
+        planner.update_cells(xy, val, rebuild=False)
+    gpu_vs_oracle(planner, oracle, cur, s, g, 2)
+    assert np.array_equal(planner.get_grid(), cur)
+    ups = some_updates(cur, 3)  # deferred, deferred, then a rebuilding one
+    planner.update_cells(*ups[0], rebuild=False)
+    planner.update_cells(*ups[1], rebuild=False)
+    planner.update_cells(*ups[2])
+    gpu_vs_oracle(planner, oracle, cur, s, g, 1)
+    ups = some_updates(cur, 3)  # deferred ones in front of a streaming frame
+    planner.set_queries(s, g, 2, 512)
+    planner.update_cells(*ups[0], rebuild=False)
+    planner.update_cells(*ups[1], rebuild=False)
+    off, cells, cost, st = planner.replan_frame(*ups[2])
+    oc, ol, ocost, _ = oracle.plan_batch(cur, s, g, 2, literal=False, max_len=512)
+    assert np.array_equal(st, ol) and cost.tobytes() == ocost.tobytes()
+    for q in range(len(s)):
+        assert np.array_equal(cells[off[q]:off[q + 1]], oc[q, :max(int(ol[q]), 0)])
+
+
 def test_neighbour_mask_map(planner):
     """Derived map K2: bit k of nb8[x+1][y+1] is the occupancy of the k-th neighbour (border = occupied)."""
     rng = np.random.default_rng(2)

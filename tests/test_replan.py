@@ -63,7 +63,8 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
         def set_queries(self, starts, goals, hchoice, max_path_len):
             self.nq = len(starts)
 
-        def update_cells(self, xy, val):
+        def update_cells(self, xy, val, rebuild=True):
+            assert not rebuild, "the frame's own call rebuilds the maps"
             assert self.lock.acquire(blocking=False), "a handle is used by one thread at a time"
             self.grid[xy[:, 0], xy[:, 1]] = val
             self.calls.append("u")
