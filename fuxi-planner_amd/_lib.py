@@ -15,14 +15,15 @@ BACKEND_HIP = 1
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
-           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_debug_read_nbmask",
+           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_debug_read_nbmask",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst")
 
 
 class Timing(C.Structure):
     _fields_ = [("search_kernel_ms", C.c_double), ("total_ms", C.c_double), ("search_launches", C.c_int64),
                 ("retried", C.c_int64), ("pops", C.c_int64), ("pushes", C.c_int64), ("far_refills", C.c_int64),
-                ("slow_pops", C.c_int64), ("table_wipes", C.c_int64), ("reused", C.c_int64), ("table_direct", C.c_int64)]
+                ("slow_pops", C.c_int64), ("table_wipes", C.c_int64), ("reused", C.c_int64), ("table_direct", C.c_int64),
+                ("waves", C.c_int64), ("waves_short", C.c_int64)]
 
 
 class FxjpsError(RuntimeError):
@@ -105,6 +106,12 @@ def load():
     L.fxjps_last_cells.argtypes = [vp, p_i32, C.c_int64]
     L.fxjps_last_timing.restype = C.c_int
     L.fxjps_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.fxjps_last_timing_device.restype = C.c_int
+    L.fxjps_last_timing_device.argtypes = [vp, C.c_int32, p_i32, p_i64, p_f64, p_i64]
+    L.fxjps_comm_info.restype = C.c_int
+    L.fxjps_comm_info.argtypes = [vp, p_i32, p_i32, p_i32]
+    L.fxjps_set_memory_share.restype = C.c_int
+    L.fxjps_set_memory_share.argtypes = [vp, C.c_int32]
     L.fxjps_selftest_sqrt.restype = C.c_int
     L.fxjps_selftest_sqrt.argtypes = [vp, C.c_uint32, C.c_uint32, p_f64]
     L.fxjps_selftest_wavemin.restype = C.c_int

@@ -131,6 +131,12 @@ struct DevCtx {
     DBuf<uint8_t> d_raw, d_img;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val;
+    // pinned staging of a cell-update list: the caller's arrays are copied here before the asynchronous H2D copy, so
+    // that they need not outlive the call (ev_upd: the last copy out of the staging buffers has completed)
+    HBuf<int32_t> h_upd_xy;
+    HBuf<uint8_t> h_upd_val;
+    hipEvent_t ev_upd = nullptr;
+    bool upd_pending = false;
     HBuf<int32_t> h_len, h_cells;
     HBuf<double> h_cost;
     HBuf<long long> h_offsets;
@@ -140,6 +146,8 @@ struct DevCtx {
     int64_t q0 = 0, nq = 0;
     double kernel_ms = 0;
     int64_t launches = 0, retried = 0;
+    uint32_t waves_used = 0;  // resident wavefronts of the last regular-pool launch
+    bool waves_short = false; // a scratch pool was granted fewer wavefronts than the batch asked for (memory budget / out of memory)
 };
 
 }  // namespace
@@ -149,6 +157,7 @@ struct fxjps {
     std::string err;
     bool have_grid = false;
     bool maps_stale = false;  // cell updates were applied without rebuilding the derived maps (fxjps_update_cells_deferred)
+    int mem_div = 1;          // handles sharing each device (fxjps_set_memory_share): the scratch budgets are divided by it
     fxjps_timing_t timing{};
     int64_t last_nq = 0;
     // persistent query set of the streaming-replan entry points (fxjps_set_queries / fxjps_replan_frame)
@@ -308,8 +317,8 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         // queries fill half of a cells/4 table, where one 4-slot bucket in seven is full and the node that meets it
         // is committed by the slow general form (config 2: 152.9 -> 146.9 ms per 10 000 queries).
         {
-            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC / (uint64_t)d.share;
-            const uint64_t cap = (d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30)) / (uint64_t)d.share;
+            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC / (uint64_t)(d.share * h->mem_div);
+            const uint64_t cap = (d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30)) / (uint64_t)(d.share * h->mem_div);
             uint32_t shift = 2;
             if (const char* e = getenv("FXJPS_TABLE_SHIFT")) shift = (uint32_t)std::max(0, atoi(e));  // measurement aid
             while (shift > 0 && full * (((uint64_t)19 << (l2e + shift))) > cap) shift--;  // 16-byte entries + the far tier (an eighth as many 18-byte entries)
@@ -324,8 +333,8 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         {
             const uint32_t lx = std::max(ceil_log2((uint64_t)d.W), 1u), ly = std::max(ceil_log2((uint64_t)d.H), 1u);
             const uint32_t ld = std::max(lx + ly, 12u);
-            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC / (uint64_t)d.share;
-            const uint64_t cap = (d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30)) / (uint64_t)d.share;
+            const uint64_t full = (uint64_t)d.n_cu * 4u * (uint64_t)fx::OCC / (uint64_t)(d.share * h->mem_div);
+            const uint64_t cap = (d.mem_total ? (uint64_t)(d.mem_total * 0.4) : ((uint64_t)32 << 30)) / (uint64_t)(d.share * h->mem_div);
             const bool allow = !(getenv("FXJPS_DIRECT") && atoi(getenv("FXJPS_DIRECT")) == 0) && !getenv("FXJPS_TABLE_LOG2");
             if (allow && ld <= 23u && full * ((uint64_t)19 << ld) <= cap) {
                 l2e = ld;
@@ -348,7 +357,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
     // Memory budget.  Pool 0 may take 60 % of the device; pool 1 (allocated while pool 0 stays resident) is sized
     // from what is free right now plus what it already holds, so that the two pools share one budget.
-    size_t budget = (d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30)) / (size_t)d.share;
+    size_t budget = (d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30)) / (size_t)(d.share * h->mem_div);
     if (pool == 1) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -361,6 +370,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     constexpr uint32_t WPBm = (uint32_t)fx::WPB - 1u;  // wavefront counts are whole blocks
     maxw &= ~WPBm;
     if (maxw < (uint32_t)fx::WPB) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
+    if (((c.nwaves + WPBm) & ~WPBm) > maxw) d.waves_short = true;
     c.nwaves = std::max((uint32_t)fx::WPB, std::min((c.nwaves + WPBm) & ~WPBm, maxw));
     ScratchCfg& cur = d.cfg[pool];
     const bool same = cur.log2_buckets == c.log2_buckets && cur.direct_ly == c.direct_ly && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
@@ -381,6 +391,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
             if (e != hipErrorOutOfMemory || c.nwaves <= (uint32_t)fx::WPB)
                 return fail(h, e == hipErrorOutOfMemory ? FXJPS_E_NOMEM : FXJPS_E_HIP, "scratch pool %d: %s", pool, hipGetErrorString(e));
             c.nwaves = std::max((uint32_t)fx::WPB, (c.nwaves / 2u) & ~WPBm);
+            d.waves_short = true;
             DBG("pool %d: out of memory, retrying with %u wavefronts", pool, c.nwaves);
         }
         cur = c;
@@ -428,6 +439,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
     waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
     waves = std::min<uint32_t>(waves, c.nwaves);
+    if (pool == 0) d.waves_used = waves;
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
     const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
@@ -457,6 +469,8 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     d.launches = 0;
     d.retried = 0;
     d.nrun = 0;
+    d.waves_used = 0;
+    d.waves_short = false;
     if (nq == 0) return FXJPS_OK;
     HIPCHK(h, d.d_starts.ensure((size_t)nq * 2));
     HIPCHK(h, d.d_goals.ensure((size_t)nq * 2));
@@ -477,7 +491,7 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
         HIPCHK(h, d.d_qstat.ensure((size_t)nq * 4));
         HIPCHK(h, hipMemsetAsync(d.d_qstat.p, 0, (size_t)nq * 4 * sizeof(unsigned long long), d.stream));
     }
-    uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC / (uint32_t)d.share;  // every wavefront the chip can hold at once
+    uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC / (uint32_t)(d.share * h->mem_div);  // every wavefront the chip can hold at once (this handle's share of them)
     full = std::max<uint32_t>(full & ~((uint32_t)fx::WPB - 1u), (uint32_t)fx::WPB);
     if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(fx::WPB, atoi(e)) & ~((uint32_t)fx::WPB - 1u);  // measurement aid
     // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
@@ -581,6 +595,7 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
 }
 
 int update_cells_async(fxjps* h, const int32_t* xy, const uint8_t* val, int64_t n, bool derive);  // (below, with the streaming entry points)
+void drain_all(fxjps* h);
 
 int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq, int hchoice, int max_len, int mode = 0) {
     if (!h) return FXJPS_E_ARG;
@@ -605,15 +620,7 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     for (int r = 0; r < nd && !rc; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
     for (int r = 0; r < nd && !rc; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
     if (rc) {
-        // copies and kernels of the other devices may still be in flight on the caller's buffers and on device
-        // buffers the next call may reallocate: drain every stream before the error leaves the library
-        const std::string keep = h->err;
-        for (auto& d : h->devs) {
-            if (hipSetDevice(d.dev) == hipSuccess) (void)hipStreamSynchronize(d.stream);
-            d.pool_clean[0] = d.pool_clean[1] = false;  // a search may have died half-way through a table
-        }
-        (void)hipGetLastError();
-        h->err = keep;
+        drain_all(h);  // before the error leaves the library
         return rc;
     }
     fxjps_timing_t& T = h->timing;
@@ -627,7 +634,11 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     T.table_wipes = 0;
     T.reused = 0;
     T.table_direct = 0;
+    T.waves = 0;
+    T.waves_short = 0;
     for (auto& d : h->devs) {
+        T.waves += d.waves_used;
+        if (d.waves_short) T.waves_short = 1;
         T.search_kernel_ms = std::max(T.search_kernel_ms, d.kernel_ms);
         T.search_launches += d.launches;
         T.retried += d.retried;
@@ -711,7 +722,20 @@ int finish_set_grid(fxjps* h, int W, int H) {
         HIPCHK(h, hipStreamSynchronize(d.stream));
     }
     h->have_grid = true;
+    h->maps_stale = false;  // (derived from the grid that was just set: a deferred update of the old grid is moot)
     return FXJPS_OK;
+}
+
+// every stream of the handle idle (error paths: copies and kernels of the other devices may still be in flight on the
+// caller's buffers and on device buffers the next call may reallocate)
+void drain_all(fxjps* h) {
+    const std::string keep = h->err;
+    for (auto& d : h->devs) {
+        if (hipSetDevice(d.dev) == hipSuccess) (void)hipStreamSynchronize(d.stream);
+        d.pool_clean[0] = d.pool_clean[1] = false;  // a search may have died half-way through a table
+    }
+    (void)hipGetLastError();
+    h->err = keep;
 }
 
 }  // namespace
@@ -755,6 +779,7 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreate(&d.ev0);
         if (e == hipSuccess) e = hipEventCreate(&d.ev1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_upd, hipEventDisableTiming);
         if (e != hipSuccess) {
             int rc = fail(nullptr, FXJPS_E_HIP, "device %d: %s", d.dev, hipGetErrorString(e));
             fxjps_destroy(h);
@@ -826,6 +851,9 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_cost.release();
         d.h_offsets.release();
         d.h_counters.release();
+        d.h_upd_xy.release();
+        d.h_upd_val.release();
+        if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);
         if (d.stream) (void)hipStreamDestroy(d.stream);
@@ -913,6 +941,7 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
         HIPCHK(h, hipStreamSynchronize(d.stream));
     }
     h->have_grid = true;
+    h->maps_stale = false;
     // :266-267 (st: + map_d - 1) / :452-453 (ccst: + map_d)
     const long long sh = variant == 0 ? 1 : 0;
     long long nsx = sx + dx - sh, nsy = sy + dy - sh, ngx = gx + dx - sh, ngy = gy + dy - sh;
@@ -991,8 +1020,11 @@ int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {
     if (out_W) *out_W = d.W;
     if (out_H) *out_H = d.H;
     if (out) {
+        // on the context's stream: it is created non-blocking, so a null-stream copy would not order behind cell
+        // updates that are still queued there (fxjps_update_cells_deferred)
         HIPCHK(h, hipSetDevice(d.dev));
-        HIPCHK(h, hipMemcpy(out, d.occ.p, (size_t)d.W * d.H, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpyAsync(out, d.occ.p, (size_t)d.W * d.H, hipMemcpyDeviceToHost, d.stream));
+        HIPCHK(h, hipStreamSynchronize(d.stream));
     }
     return FXJPS_OK;
 }
@@ -1076,15 +1108,27 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     for (auto& d : h->devs) {
         HIPCHK(h, hipSetDevice(d.dev));
         if (n > 0) {
+            // The caller's arrays go through pinned staging buffers of the context: the call may return while the H2D
+            // copies are still queued (fxjps_update_cells_deferred), and the caller owns its buffers again at once.
+            // Before the staging buffers (and the device list the queued kernel reads) are reused, the previous
+            // update's copies and kernel must be through: ev_upd.
+            if (d.upd_pending) HIPCHK(h, hipEventSynchronize(d.ev_upd));
+            d.upd_pending = false;
             HIPCHK(h, d.d_upd_xy.ensure((size_t)n * 2));
             HIPCHK(h, d.d_upd_val.ensure((size_t)n));
-            HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, xy, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-            HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, val, (size_t)n, hipMemcpyHostToDevice, d.stream));
+            HIPCHK(h, d.h_upd_xy.ensure((size_t)n * 2));
+            HIPCHK(h, d.h_upd_val.ensure((size_t)n));
+            memcpy(d.h_upd_xy.p, xy, (size_t)n * 2 * sizeof(int32_t));
+            memcpy(d.h_upd_val.p, val, (size_t)n);
+            HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, d.h_upd_xy.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+            HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, d.h_upd_val.p, (size_t)n, hipMemcpyHostToDevice, d.stream));
         }
         if (n > 0) {
             hipLaunchKernelGGL(fx::k_update_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.occ.p,
                                d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p, (long long)n);
             HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipEventRecord(d.ev_upd, d.stream));
+            d.upd_pending = true;
         }
         if (derive) {
             int rc = derive_maps(h, d);
@@ -1162,6 +1206,8 @@ int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     if (!h->q_set) return fail(h, FXJPS_E_ARG, "fxjps_replan_frame before fxjps_set_queries");
     const int64_t nq = (int64_t)h->q_starts.size() / 2;
     if (nq > 0 && (!out_offsets || !out_len || !out_cost)) return fail(h, FXJPS_E_ARG, "NULL output array");
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_replan_frame before fxjps_set_grid");
+    if (n < 0 || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
     // ---- exact reuse.  Which read-set tiles does this frame's update touch?  Derived data of a cell depends on the
     // occupancy within Chebyshev distance 1, so every changed cell marks the tiles of its 3 x 3 neighbourhood; a
     // stored result whose read set (see ReadSet in the kernels) misses all of them is what a from-scratch search
@@ -1209,8 +1255,12 @@ int fxjps_replan_frame(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     }
     // the frame's map update is queued in front of the search on the same streams: the first host wait of the frame
     // is the one for the search results
+    h->q_results_valid = false;  // (set again below, once the frame is complete)
     int rc = update_cells_async(h, xy, val, n, true);
-    if (rc) return rc;
+    if (rc) {
+        drain_all(h);  // the devices in front of the failing one have the update queued
+        return rc;
+    }
     rc = plan_core(h, h->q_starts.data(), h->q_goals.data(), nq, h->q_hchoice, h->q_max_len, mode);
     if (rc) return rc;
     h->q_results_valid = track;
@@ -1271,6 +1321,55 @@ int fxjps_plan_batch(fxjps_t* h, const int32_t* starts_xy, const int32_t* goals_
     }
     h->timing.total_ms = (now_s() - t0) * 1e3;
     if (out_seconds_total) *out_seconds_total = now_s() - t0;
+    return FXJPS_OK;
+}
+
+int fxjps_set_memory_share(fxjps_t* h, int32_t handles_per_device) {
+    if (!h) return FXJPS_E_ARG;
+    if (handles_per_device < 1 || handles_per_device > 64) return fail(h, FXJPS_E_ARG, "handles_per_device must be 1..64");
+    if (h->mem_div != handles_per_device) {
+        h->mem_div = handles_per_device;
+        for (auto& d : h->devs) {  // the next batch sizes its pools again
+            d.cfg[0] = ScratchCfg();
+            d.cfg[1] = ScratchCfg();
+            d.pool_clean[0] = d.pool_clean[1] = false;
+        }
+    }
+    return FXJPS_OK;
+}
+
+int fxjps_comm_info(fxjps_t* h, int32_t* out_contexts, int32_t* out_devices, int32_t* out_rccl_ranks) {
+    if (!h) return FXJPS_E_ARG;
+    if (out_contexts) *out_contexts = (int32_t)h->devs.size();
+    if (out_devices) {
+        int n = 0;
+        for (size_t a = 0; a < h->devs.size(); a++) {
+            bool first = true;
+            for (size_t b = 0; b < a; b++)
+                if (h->devs[b].dev == h->devs[a].dev) first = false;
+            n += first ? 1 : 0;
+        }
+        *out_devices = n;
+    }
+    if (out_rccl_ranks) {
+        *out_rccl_ranks = 0;
+        if (h->rccl && !h->comms.empty() && h->comms[0]) {
+            typedef int (*nccl_count_t)(void*, int*);
+            auto count = (nccl_count_t)dlsym(h->rccl, "ncclCommCount");
+            int n = 0;
+            if (count && count(h->comms[0], &n) == 0) *out_rccl_ranks = n;
+        }
+    }
+    return FXJPS_OK;
+}
+
+int fxjps_last_timing_device(fxjps_t* h, int32_t ctx, int32_t* out_device, int64_t* out_nq, double* out_kernel_ms, int64_t* out_waves) {
+    if (!h || ctx < 0 || ctx >= (int32_t)h->devs.size()) return FXJPS_E_ARG;
+    const DevCtx& d = h->devs[(size_t)ctx];
+    if (out_device) *out_device = d.dev;
+    if (out_nq) *out_nq = d.nq;
+    if (out_kernel_ms) *out_kernel_ms = d.kernel_ms;
+    if (out_waves) *out_waves = d.waves_used;
     return FXJPS_OK;
 }
 
@@ -1395,7 +1494,12 @@ int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf) {
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
     DevCtx& d = h->devs[0];
     HIPCHK(h, hipSetDevice(d.dev));
-    HIPCHK(h, hipMemcpy2D(buf, (size_t)d.PH, d.nb8.p, (size_t)d.NS, (size_t)d.PH, (size_t)d.PW, hipMemcpyDeviceToHost));
+    if (h->maps_stale) {  // deferred cell updates: the maps follow the grid first
+        int rc = update_cells_async(h, nullptr, nullptr, 0, true);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)d.PH, d.nb8.p, (size_t)d.NS, (size_t)d.PH, (size_t)d.PW, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
     return FXJPS_OK;
 }
 

@@ -264,6 +264,28 @@ class Planner(object):
         self._chk(self._L.fxjps_last_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}
 
+    def timing_per_context(self):
+        """Per context of the handle (one per entry of `devices`): device, queries of its shard, search-kernel ms,
+        resident wavefronts of the last batch."""
+        out = []
+        for r in range(len(self.devices)):
+            dev, nq, ms, wv = C.c_int32(), C.c_int64(), C.c_double(), C.c_int64()
+            self._chk(self._L.fxjps_last_timing_device(self._h, r, C.byref(dev), C.byref(nq), C.byref(ms), C.byref(wv)))
+            out.append({"device": dev.value, "queries": nq.value, "kernel_ms": ms.value, "waves": wv.value})
+        return out
+
+    def comm_info(self):
+        """-> {"contexts", "devices", "rccl_ranks"}: rccl_ranks is ncclCommCount of the handle's communicator (0 while
+        no collective has run: one device, or contexts sharing a device)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.fxjps_comm_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"contexts": a.value, "devices": b.value, "rccl_ranks": c.value}
+
+    def set_memory_share(self, handles_per_device):
+        """This handle is one of `handles_per_device` on its device(s): scratch pools and resident wavefronts are sized
+        for that share (FramePipeline sets it)."""
+        self._chk(self._L.fxjps_set_memory_share(self._h, int(handles_per_device)))
+
     # -- test hooks
     def selftest_sqrt(self, n0, n1):
         out = np.empty(n1 - n0, dtype=np.float64)

@@ -57,12 +57,14 @@ class FramePipeline(object):
         self.k = int(k)
         self.planners = [Planner([device]) for _ in range(self.k)]
         for p in self.planners:
+            p.set_memory_share(self.k)  # K handles on one device: each sizes its scratch for a K-th of it
             p.set_grid_occ(occ)
             p.set_queries(starts, goals, hchoice, max_path_len)
         self._backlog = [[] for _ in range(self.k)]  # updates a handle has not applied yet, oldest first
         self._busy = [None] * self.k
         self._pool = ThreadPoolExecutor(max_workers=self.k)
         self._n = 0
+        self._broken = None  # the exception that stopped the pipeline: a handle that failed has lost updates
 
     def _run(self, j, updates):
         p = self.planners[j]
@@ -72,25 +74,38 @@ class FramePipeline(object):
 
     def submit(self, xy, val):
         """Queue one frame.  Blocks only while the handle whose turn it is still plans its previous frame."""
+        if self._broken is not None:
+            raise RuntimeError("FramePipeline stopped by an earlier failure: %r" % (self._broken,))
         xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
         val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
+        j = self._n % self.k
+        # the handle's previous frame first: if it failed, the handle has popped updates it never applied and plans on
+        # a stale grid from here on -- the pipeline stops instead (nothing of the new frame has been queued yet)
+        if self._busy[j] is not None:
+            try:
+                self._busy[j].result()
+            except BaseException as e:
+                self._broken = e
+                raise
         for b in self._backlog:
             b.append((xy, val))
-        j = self._n % self.k
         self._n += 1
-        if self._busy[j] is not None:
-            self._busy[j].result()
         updates, self._backlog[j] = self._backlog[j], []
         self._busy[j] = self._pool.submit(self._run, j, updates)
         return self._busy[j]
 
     def close(self):
-        for f in self._busy:
-            if f is not None:
-                f.result()
-        self._pool.shutdown(wait=True)
-        for p in self.planners:
-            p.close()
+        try:
+            for f in self._busy:
+                if f is not None:
+                    try:
+                        f.result()
+                    except BaseException as e:  # (the caller saw it through the frame's own future)
+                        self._broken = self._broken or e
+        finally:
+            self._pool.shutdown(wait=True)
+            for p in self.planners:
+                p.close()
 
     def __enter__(self):
         return self

@@ -132,8 +132,9 @@ int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* ou
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
 
 /* fxjps_update_cells without the rebuild of the derived maps: the updates are applied to the resident grid (calls are
- * applied in order; one update per cell within a call) and the maps are rebuilt once by the next fxjps_update_cells,
- * fxjps_plan_batch* or fxjps_replan_frame.  For hosts that hand a handle several frames' updates before it plans
+ * applied in order; one update per cell within a call; xy / val are copied before the call returns, which it may do
+ * while the update is still queued on the device -- every reader of the grid, fxjps_get_grid included, is ordered
+ * behind it) and the maps are rebuilt once by the next fxjps_update_cells, fxjps_plan_batch* or fxjps_replan_frame.  For hosts that hand a handle several frames' updates before it plans
  * again (fuxi_planner_amd.replan.FramePipeline; scripts/global_planner_st.py:15-25 delivers one map message per
  * callback, the node plans once per tick). */
 int fxjps_update_cells_deferred(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
@@ -197,8 +198,27 @@ typedef struct fxjps_timing {
     int64_t reused;          /* fxjps_replan_frame: stored results returned without a search (their read set was untouched) */
     int64_t table_direct;    /* 1: the last batch ran on visited tables indexed by the cell (grids of up to 2^20 slots), 0: on
                                 hashed tables of 4-slot buckets (larger grids; FXJPS_DIRECT=0) */
+    int64_t waves;           /* resident wavefronts (= queries in flight) the last batch ran with, summed over the contexts */
+    int64_t waves_short;     /* 1: a scratch pool was granted fewer wavefronts than the batch asked for (memory budget of the
+                                handle, or the device ran out of memory): the batch ran, with less parallelism */
 } fxjps_timing_t;
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
+
+/* Per-context figures of the last batch (ctx = 0 .. contexts-1, the order of device_ids at fxjps_create): the device
+ * it ran on, the queries of its contiguous shard, the HIP-event time of its search kernel launches, its resident
+ * wavefronts.  Any out pointer may be NULL. */
+int fxjps_last_timing_device(fxjps_t* h, int32_t ctx, int32_t* out_device, int64_t* out_nq, double* out_kernel_ms,
+                             int64_t* out_waves);
+
+/* What the handle spans: its contexts (entries of device_ids), the distinct devices among them, and the number of
+ * ranks of its RCCL communicator (ncclCommCount; 0 while no collective has run: a single device, or contexts that
+ * share one -- the grid then travels by device-to-device copies).  north_star: one ncclBroadcast of the grid over
+ * xGMI per fxjps_set_grid, no other collective. */
+int fxjps_comm_info(fxjps_t* h, int32_t* out_contexts, int32_t* out_devices, int32_t* out_rccl_ranks);
+
+/* Several handles on one device (fuxi_planner_amd.replan.FramePipeline keeps K of them): each handle sizes its scratch
+ * pools and its resident wavefronts as if it owned 1/handles_per_device of every device it spans.  Default 1. */
+int fxjps_set_memory_share(fxjps_t* h, int32_t handles_per_device);
 
 /* Device self-test: sqrt((double)n) for n in [n0, n1) written to out (host).
  * Used by the tests to prove the device square root is the correctly rounded

@@ -92,6 +92,48 @@ def test_config4_shard_125k(planner, oracle):
     assert_same(merge_csr(halves), res)
 
 
+def test_config4_full_1m_in_eight_shards(planner, oracle):
+    """BASELINE config 4 at its stated size: the 1 000 000 queries through a handle of eight contexts (the exact
+    8-way contiguous split of north_star, here all on GPU 0: everything of the in-library multi-device path but the
+    collective) -- byte-identical to ONE 1 M-query batch on a one-context handle; shard edges are
+    shard_bounds(10**6, r, 8); 2 500 queries of EACH shard against the oracle; invariants on a sample; a query has no
+    path iff its goal lies in another 4-connected component (jps1.py:183-192: calls share nothing)."""
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import synth
+    from fuxi_planner_amd.distributed import shard_bounds
+    occ = synth.synth_grid(1024, 1024, 1, 0.20)
+    nq = 10 ** 6
+    s, g = synth.synth_queries(occ, 1, nq)
+    planner.set_grid_occ(occ)
+    one = planner.plan_batch(s, g, 2, 1024)
+    assert (one[3] >= 0).all() and planner.timing()["retried"] == 0
+    with fx.Planner([0] * 8) as p8:
+        p8.set_grid_occ(occ)
+        assert p8.comm_info() == {"contexts": 8, "devices": 1, "rccl_ranks": 0}
+        res = p8.plan_batch(s, g, 2, 1024)
+        per = p8.timing_per_context()
+        assert [c["queries"] for c in per] == [shard_bounds(nq, r, 8)[1] - shard_bounds(nq, r, 8)[0] for r in range(8)]
+        assert all(c["kernel_ms"] > 0 and c["waves"] > 0 for c in per) and p8.timing()["retried"] == 0
+        print("config 4, eight contexts on one GPU: kernel ms per shard", [round(c["kernel_ms"], 1) for c in per])
+    assert_same(res, one)
+    off, cells, cost, st = res
+    # every shard against the oracle: 2 500 queries spread over it (the first shard is test_config4_shard_125k's)
+    for r in range(8):
+        lo, hi = shard_bounds(nq, r, 8)
+        sel = np.linspace(lo, hi - 1, 2500).astype(np.int64)
+        o_off, o_cells, o_cost, o_len = oracle_csr(oracle, occ, s[sel], g[sel], 2, 1024)
+        assert np.array_equal(st[sel], o_len) and cost[sel].tobytes() == o_cost.tobytes(), r
+        assert np.array_equal(np.concatenate([cells[off[q]:off[q + 1]] for q in sel]), o_cells), r
+    sel = np.arange(7, nq, 997)
+    o2 = np.zeros(len(sel) + 1, dtype=np.int64)
+    o2[1:] = np.cumsum(np.maximum(st[sel], 0))
+    path_invariants(occ, s[sel], g[sel], o2, np.concatenate([cells[off[q]:off[q + 1]] for q in sel]), cost[sel], st[sel])
+    from scipy import ndimage
+    lab, _ = ndimage.label(occ == 0, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    assert np.array_equal(st > 0, lab[s[:, 0], s[:, 1]] == lab[g[:, 0], g[:, 1]])
+    planner.set_grid_occ(synth.synth_grid(64, 64, 1, 0.2))  # (gives the large batch buffers' grid back)
+
+
 # ------------------------------------------------------------------ config 3: 4096 x 4096, 100 000 queries
 def test_config3_full(planner, oracle):
     from fuxi_planner_amd import synth
@@ -106,6 +148,11 @@ def test_config3_full(planner, oracle):
     o_off, o_cells, o_cost, o_len = oracle_csr(oracle, occ, s[:n_or], g[:n_or], 2, 4096, nthreads=min(NTHREADS, 64))
     assert np.array_equal(st[:n_or], o_len) and cost[:n_or].tobytes() == o_cost.tobytes()
     assert np.array_equal(off[:n_or + 1], o_off) and np.array_equal(cells[:off[n_or]], o_cells)
+    # ... 8 000 more spread evenly over the other 98 000 (a wrong-but-valid path passes the invariants below, not this)
+    strat = np.linspace(n_or, nq - 1, 8000).astype(np.int64)
+    o_off, o_cells, o_cost, o_len = oracle_csr(oracle, occ, s[strat], g[strat], 2, 4096, nthreads=min(NTHREADS, 64))
+    assert np.array_equal(st[strat], o_len) and cost[strat].tobytes() == o_cost.tobytes()
+    assert np.array_equal(np.concatenate([cells[off[q]:off[q + 1]] for q in strat]), o_cells)
     sel = np.arange(n_or, nq, 197)  # ... and size-independent invariants on a sample of the rest
     o2 = np.zeros(len(sel) + 1, dtype=np.int64)
     o2[1:] = np.cumsum(np.maximum(st[sel], 0))

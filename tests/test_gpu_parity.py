@@ -282,6 +282,25 @@ def test_deferred_cell_updates(planner, oracle):
     for q in range(len(s)):
         assert np.array_equal(cells[off[q]:off[q + 1]], oc[q, :max(int(ol[q]), 0)])
 
+    # readers of the grid are ordered behind queued updates (the stream is non-blocking: a null-stream copy is not),
+    # and the update arrays are the library's the moment the call returns: temporaries, overwritten at once here
+    big = synth.synth_grid(1024, 1024, 3, 0.20)
+    planner.set_grid_occ(big)
+    for rep in range(4):
+        idx = rng.choice(1024 * 1024, 300000, replace=False)
+        xy = np.stack([idx // 1024, idx % 1024], 1).astype(np.int32)
+        val = rng.integers(0, 2, len(xy)).astype(np.uint8)
+        big[xy[:, 0], xy[:, 1]] = val
+        planner.update_cells(xy, val, rebuild=False)
+        xy[:] = 0
+        val[:] = 1 - big[0, 0]
+        del xy, val
+        assert np.array_equal(planner.get_grid(), big), rep
+    nb = planner.debug_nbmask()  # (rebuilds the maps the deferred updates left stale)
+    pad = np.ones((1026, 1026), dtype=np.uint8)
+    pad[1:-1, 1:-1] = big
+    assert np.array_equal(nb[1:-1, 1:-1] & 1, pad[0:-2, 0:-2])  # bit 0 = the (-1, -1) neighbour
+
 
 def test_neighbour_mask_map(planner):
     """Derived map K2: bit k of nb8[x+1][y+1] is the occupancy of the k-th neighbour (border = occupied)."""

@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from fuxi_planner_amd.replan import ReplanThrottle
 
@@ -57,6 +58,9 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
             self.lock = threading.Lock()
             FakePlanner.made.append(self)
 
+        def set_memory_share(self, k):
+            self.share = k
+
         def set_grid_occ(self, occ):
             self.grid = occ.copy()
 
@@ -105,3 +109,29 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
         for j, p in enumerate(FakePlanner.made):
             assert "".join(p.calls).startswith("u" * j + "r")
             assert p.calls.count("r") == len(range(j, len(frames), k))
+            assert p.share == k
+
+    # a handle that fails stops the pipeline: its frame's future carries the exception, the submit whose turn is that
+    # handle raises it BEFORE anything of the new frame is queued, later submits are refused, close() still closes
+    class Boom(RuntimeError):
+        pass
+
+    FakePlanner.made = []
+    pipe = FramePipeline(0, 2, occ, np.zeros((4, 2), np.int32), np.ones((4, 2), np.int32))
+    orig = FakePlanner.made[1].replan_frame
+    FakePlanner.made[1].replan_frame = lambda xy, val: (_ for _ in ()).throw(Boom("device lost"))
+    f0 = pipe.submit(*frames[0])
+    f1 = pipe.submit(*frames[1])
+    f2 = pipe.submit(*frames[2])
+    assert np.array_equal(f0.result(), want[0]) and np.array_equal(f2.result(), want[2])
+    with pytest.raises(Boom):
+        f1.result()
+    n_before = pipe._n
+    with pytest.raises(Boom):
+        pipe.submit(*frames[3])          # handle 1's turn
+    assert pipe._n == n_before and all(len(b) == 0 or b is pipe._backlog[1] or len(b) == 1 for b in pipe._backlog)
+    with pytest.raises(RuntimeError):
+        pipe.submit(*frames[3])
+    FakePlanner.made[1].replan_frame = orig
+    pipe.close()
+    assert all(p.closed for p in FakePlanner.made)
