@@ -9,28 +9,33 @@ generator fuxi-planner_amd/synth.py):
     c2h1     the same with hchoice 1 (octile x10/x14)
     c3       BASELINE config 3: 4096^2, 100 000 queries
     c4shard  one GPU's share of BASELINE config 4: 1024^2, 125 000 queries
-    c4       BASELINE config 4 itself: 1 000 000 queries split over the N ranks (strong scaling)
+    c4       BASELINE config 4 itself: 1 000 000 queries split over the N GPUs (strong scaling; N = 1: all of them)
     c5       BASELINE config 5, streaming replan: a step is one frame = toggle 10 % of the cells + rebuild the maps +
              plan the 1 000 persistent queries (SURVEY 8d toggle stream); c5low = the same with 0.1 % toggles;
              c5local = one 64 x 64 window re-observed per frame (the exact-reuse case of fxjps_replan_frame);
-             c5pipe = config 5 with eight frames in flight (fuxi_planner_amd.replan.FramePipeline: eight planner handles
-             on the GPU take the frames in turn): the sustained frame rate, `--steps 32 --warmup 8` for a steady state
+             c5pipe = config 5 with frames in flight (fuxi_planner_amd.replan.FramePipeline: K planner handles on the
+             GPU take the frames in turn): sustained frames/s and p50 / p99 submit-to-paths latency over the 600 frames
+             SURVEY 8d prescribes (its default --steps)
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-With N ranks (one process per GPU, launched by torch.distributed.run) rank r plans its own nq-query slice of the same
-query stream (weak scaling; c4: the r-th N-th of the 1 M queries, strong scaling); the grid is built on rank 0 and
-broadcast once with RCCL; no other collective is on the data path.  `--inlib` instead drives all N GPUs from ONE
-process through the library's own multi-device handle (fxjps_create(n_dev = N): ncclCommInitAll + one ncclBroadcast,
-no torch).
+N > 1, two ways (contiguous query shards, one broadcast of the grid over xGMI, no other collective):
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE set): one process per GPU,
+    rank r plans its own nq-query slice (weak scaling; c4: the r-th N-th of the 1 M queries), the grid is built on rank
+    0 and broadcast once with RCCL through torch.distributed;
+  * plain `python bench.py --gpus N` (no WORLD_SIZE): ONE process drives all N GPUs through the library's own
+    multi-device handle -- fxjps_create(n_dev = N): ncclCommInitAll + one ncclBroadcast, no torch anywhere.
 
-Prints ONE JSON line on rank 0 (see the driver contract); adds `roofline` (HBM bound, algorithmic bytes / HIP-event
-kernel time) and, at N = 1, `cpu_baseline` (the C oracle on the host cores, bounded sample).
+Prints ONE JSON line on rank 0 (the driver contract) with `roofline` (HBM bound, algorithmic bytes / HIP-event kernel
+time), at N = 1 `cpu_baseline` (the C oracle on the host cores, bounded sample), and -- default workload only --
+`config.also`: the other BASELINE workloads measured right behind the timed region of the headline (c4shard and c5pipe
+at N = 1; the 1 M queries of c4 split N ways at N > 1), so that they are in the driver's record too.
 """
 import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+DEFAULT_STEPS = {"c5pipe": (600, 16)}  # workload -> (steps, warmup); everything else 5 / 2
 
 
 def kernel_src_sha16():
@@ -50,102 +56,64 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5pipe"])
-    ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe: planner handles taking the frames in turn (0: the workload's)")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
-    a = ap.parse_args()
-    if a.workload == "c5pipe":
-        # one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run one
-        # after the other; read by the HIP runtime when it initialises (nothing has touched the GPU yet)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+class Ctx(object):
+    """What every workload of one bench.py process shares: ranks, the planner handle, the torch plumbing (if any)."""
+    pass
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.inlib:
-        if world > 1:
-            raise SystemExit("--inlib is a single-process mode: start it without torch.distributed.run")
-    elif world != a.gpus:
-        raise SystemExit("--gpus %d needs one process per GPU: launch with\n  python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...\n"
-                         "(or add --inlib to drive all GPUs from one process through the library's multi-device handle)"
-                         % (a.gpus, a.gpus, a.gpus))
 
-    import fuxi_planner_amd as fx
+def make_frames(synth, occ, starts, goals, wl, n):
+    """The toggle stream is input: generated before the timed region.  -> (frames, grid after the last one)"""
+    W, H = occ.shape
+    keep = np.zeros((W, H), dtype=bool)
+    keep[starts[:, 0], starts[:, 1]] = True
+    keep[goals[:, 0], goals[:, 1]] = True
+    g = occ.copy()
+    frames = []
+    for fr in range(n):
+        xy, val = synth.frame_update(g, keep, fr, wl)
+        synth.apply_toggles(g, xy, val)
+        frames.append((xy, val))
+    return frames, g
+
+
+def measure(cx, name, steps, warmup, frames_in_flight=0):
+    """Run one workload: W untimed steps, then exactly K timed ones bracketed by a barrier + device sync on both sides,
+    MAX over ranks.  -> dict (rank 0 fills everything; the others return the timing only)."""
     from fuxi_planner_amd import synth
-    from fuxi_planner_amd.distributed import ShardedPlanner, shard_bounds
-
-    with open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")) as f:
-        WL = json.load(f)
-    wl = WL[a.workload]
+    from fuxi_planner_amd.distributed import shard_bounds
+    wl = dict(cx.WL[name])
     W, H, nq, hchoice, mpl = wl["W"], wl["H"], wl["nq"], wl["hchoice"], wl["max_path_len"]
     streaming = "toggle_frac" in wl
     strong = bool(wl.get("strong"))
-    n_units = a.gpus  # GPUs taking part
-
-    torch = dist = None
-    # Bring-up aid for 1-GPU boxes (never set by the driver): FXJPS_BENCH_BACKEND=gloo runs every rank on
-    # device 0 with a host-side broadcast, to exercise the multi-rank code path without a second GPU.
-    backend = os.environ.get("FXJPS_BENCH_BACKEND", "nccl")
-    dev_index = 0 if backend == "gloo" else local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(dev_index)
-        dist.init_process_group(backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
-
-    planner = fx.Planner(list(range(a.gpus)) if a.inlib else [dev_index])
+    n_units = cx.gpus
+    planner = cx.planner
     occ = synth.synth_grid(W, H, wl["grid_seed"], wl["p"])  # every rank needs it to draw its queries
-    if world > 1:
-        sp = ShardedPlanner(planner, device="cpu" if backend == "gloo" else "cuda:%d" % dev_index)
-        sp.set_grid(occ if rank == 0 else None)  # one RCCL broadcast of W*H bytes over xGMI
+    if cx.world > 1:
+        cx.sp.set_grid(occ if cx.rank == 0 else None)  # one RCCL broadcast of W*H bytes over xGMI
     else:
-        planner.set_grid_occ(occ)  # --inlib with N > 1: H2D to the first device + ncclBroadcast inside the library
+        planner.set_grid_occ(occ)  # in-library N > 1: H2D to the first device + ncclBroadcast inside the library
     if strong:
-        lo, hi = shard_bounds(nq, rank, world) if world > 1 else (0, nq)
+        lo, hi = shard_bounds(nq, cx.rank, cx.world) if cx.world > 1 else (0, nq)
         starts, goals = synth.synth_queries(occ, wl["qseed"], hi - lo, first=lo)
-    elif a.inlib:
-        starts, goals = synth.synth_queries(occ, wl["qseed"], nq * a.gpus)  # the library shards them contiguously
+    elif cx.inlib:
+        starts, goals = synth.synth_queries(occ, wl["qseed"], nq * cx.gpus)  # the library shards them contiguously
     else:
-        starts, goals = synth.synth_queries(occ, wl["qseed"], nq, first=rank * nq)
+        starts, goals = synth.synth_queries(occ, wl["qseed"], nq, first=cx.rank * nq)
     n_local = len(starts)
 
-    frames = []
-    if streaming:  # the toggle stream is input: generated before the timed region
-        keep = np.zeros((W, H), dtype=bool)
-        keep[starts[:, 0], starts[:, 1]] = True
-        keep[goals[:, 0], goals[:, 1]] = True
-        g = occ.copy()
-        for fr in range(a.warmup + a.steps):
-            xy, val = synth.frame_update(g, keep, fr, wl)
-            synth.apply_toggles(g, xy, val)
-            frames.append((xy, val))
-
-    def sync():
-        if world > 1:
-            torch.cuda.synchronize()
-            if backend == "nccl":
-                dist.barrier(device_ids=[dev_index])
-            else:
-                dist.barrier()
-
+    frames, g_last = [], occ
     pipe = None
-    if streaming and wl.get("frames_in_flight"):
-        if world > 1 or a.inlib:
-            raise SystemExit("c5pipe is a single-GPU workload")
-        if a.frames_in_flight > 0:
-            wl["frames_in_flight"] = a.frames_in_flight
-        from fuxi_planner_amd.replan import FramePipeline
-        pipe = FramePipeline(dev_index, int(wl["frames_in_flight"]), occ, starts, goals, hchoice, mpl)
-    elif streaming:
-        planner.set_queries(starts, goals, hchoice, mpl)
+    if streaming:
+        frames, g_last = make_frames(synth, occ, starts, goals, wl, warmup + steps)
+        if wl.get("frames_in_flight"):
+            if cx.world > 1 or cx.gpus > 1:
+                raise SystemExit("c5pipe is a single-GPU workload")
+            if frames_in_flight > 0:
+                wl["frames_in_flight"] = frames_in_flight
+            from fuxi_planner_amd.replan import FramePipeline
+            pipe = FramePipeline(cx.dev_index, int(wl["frames_in_flight"]), occ, starts, goals, hchoice, mpl)
+        else:
+            planner.set_queries(starts, goals, hchoice, mpl)
 
     def step(i):
         if streaming:  # one call per frame: cell updates + map rebuild + search of the persistent queries
@@ -154,21 +122,19 @@ def main():
             off, cells, cost, status = planner.plan_batch(starts, goals, hchoice, mpl)  # blocking: results are in host memory
         return status, planner.timing()
 
-    kernel_ms = []
+    kernel_ms, per_ctx = [], None
     status = None
-    retried = 0
-    reused = 0
-    direct = 0
-    frame_latency_ms = None
+    retried = reused = direct = 0
+    waves = waves_short = 0
+    lat = None
     if pipe is not None:  # frames in flight: submit them all, the pipeline hands each to the next free handle
-        for f in [pipe.submit(*frames[i]) for i in range(a.warmup)]:
+        for f in [pipe.submit(*frames[i]) for i in range(warmup)]:
             f.result()
+        t_sub, t_done, futs = [], {}, []
         t0 = time.perf_counter()
-        t_sub, t_done = [], {}
-        futs = []
-        for i in range(a.steps):
+        for i in range(steps):
             t_sub.append(time.perf_counter())  # (submit blocks while the handle whose turn it is still plans)
-            f = pipe.submit(*frames[a.warmup + i])
+            f = pipe.submit(*frames[warmup + i])
             f.add_done_callback(lambda _f, _i=i: t_done.__setitem__(_i, time.perf_counter()))
             futs.append(f)
         res = [f.result() for f in futs]
@@ -177,44 +143,176 @@ def main():
             raise SystemExit("bench: queries failed")
         status = res[-1][3]  # (the last frame's: the CPU baseline below plans on that frame's grid)
         direct = 1
-        kernel_ms = [elapsed / a.steps * 1e3]  # (the launches of the frames overlap: the frame period stands in)
-        time.sleep(0.01)
-        frame_latency_ms = float(np.mean([(t_done[i] - t_sub[i]) * 1e3 for i in range(a.steps) if i in t_done]))
+        kernel_ms = [elapsed / steps * 1e3]  # (the launches of the frames overlap: the frame period stands in)
+        time.sleep(0.02)
+        lat = np.array([(t_done[i] - t_sub[i]) * 1e3 for i in range(steps) if i in t_done])
+        tm = [p.timing() for p in pipe.planners]
+        waves = int(sum(t["waves"] for t in tm))
+        waves_short = int(any(t["waves_short"] for t in tm))
         pipe.close()
     else:
-        for i in range(a.warmup):
+        for i in range(warmup):
             step(i)
-        sync()
+        cx.sync()
         t0 = time.perf_counter()
-        for i in range(a.steps):
-            status, tm = step(a.warmup + i)
+        for i in range(steps):
+            status, tm = step(warmup + i)
             kernel_ms.append(tm["search_kernel_ms"])
             retried += tm["retried"]
             reused += tm["reused"]
             direct = tm.get("table_direct", 0)
-        sync()
+            waves, waves_short = int(tm["waves"]), int(tm["waves_short"])
+        cx.sync()
         elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda:%d" % dev_index)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        per_ctx = planner.timing_per_context()  # (of the last step)
+    k_ms = float(np.mean(kernel_ms))
+    k_all = [k_ms]
+    if cx.world > 1:
+        t = cx.torch.tensor([elapsed, k_ms], dtype=cx.torch.float64, device=cx.tdev)
+        allk = [cx.torch.zeros_like(t) for _ in range(cx.world)]
+        cx.dist.all_gather(allk, t)
+        elapsed = max(float(x[0]) for x in allk)
+        k_all = [float(x[1]) for x in allk]
+    elif per_ctx is not None and len(per_ctx) > 1:
+        k_all = [c["kernel_ms"] for c in per_ctx]
     if (status < 0).any():
         raise SystemExit("bench: %d queries failed" % int((status < 0).sum()))
+    if cx.rank != 0:
+        return None
 
-    if rank == 0:
-        total_q = nq if strong else nq * n_units  # queries all ranks planned per step
-        value = total_q * a.steps / elapsed
-        k_ms = float(np.mean(kernel_ms))
-        # algorithmic bytes of what rank 0 launched (cells + 16 * (pushes + pops), literal reference run)
-        if streaming:
-            per = wl.get("algorithmic_bytes_per_frame") or []
-            fr = [per[a.warmup + i] for i in range(a.steps) if a.warmup + i < len(per)]
-            algo = float(np.mean(fr)) if len(fr) == a.steps else None  # frames beyond the committed counts: unknown
-        elif wl.get("algorithmic_bytes") is None:
-            algo = None
-        else:  # weak: rank 0 plans exactly the committed workload; strong: the mean shard
-            algo = float(wl["algorithmic_bytes"]) / (n_units if strong else 1)
-        achieved = algo / (k_ms * 1e-3) / 1e9 if algo else None
+    total_q = nq if strong else nq * n_units  # queries all ranks planned per step
+    # algorithmic bytes of what rank 0 launched (cells + 16 * (pushes + pops), literal reference run)
+    if streaming:
+        per = wl.get("algorithmic_bytes_per_frame") or []
+        fr = [per[warmup + i] for i in range(steps) if warmup + i < len(per)]
+        algo = float(np.mean(fr)) if len(fr) == steps else None  # frames beyond the committed counts: unknown
+    elif wl.get("algorithmic_bytes") is None:
+        algo = None
+    else:  # weak: each device plans exactly the committed workload; strong: the mean shard
+        algo = float(wl["algorithmic_bytes"]) / (n_units if strong else 1)
+    k_dev = max(k_all) if (cx.inlib and cx.gpus > 1) else k_ms  # the kernel time the algorithmic bytes of ONE device go against
+    achieved = algo / (k_dev * 1e-3) / 1e9 if algo else None
+    out = {
+        "workload": name, "W": W, "H": H, "hchoice": hchoice, "streaming": streaming, "strong": strong,
+        "describe": wl["describe"], "value": total_q * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps, "warmup": warmup, "total_q": total_q, "n_local": n_local, "status": status, "starts": starts, "goals": goals,
+        "grid_now": g_last if streaming else None, "occ": occ, "mpl": mpl,
+        "kernel_ms": k_dev, "kernel_ms_per_device": k_all, "algo": algo, "achieved": achieved,
+        "frac": achieved / HBM_PEAK_GBS if achieved else None, "retried": int(retried), "reused": reused, "direct": direct,
+        "waves": waves, "waves_short": waves_short, "wl": wl, "frames": frames,
+        "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and name not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
+    }
+    if streaming:
+        out["frames_per_s"] = steps / elapsed
+        out["cells_sent_per_frame"] = int(len(frames[0][1]))
+        out["results_reused_per_frame"] = reused / steps
+    if pipe is not None:
+        out["frames_in_flight"] = int(wl["frames_in_flight"])
+        out["latency_ms"] = {"mean": float(lat.mean()), "p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                             "max": float(lat.max()), "frames": int(len(lat))}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5pipe"])
+    ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N) (the default when "
+                    "bench.py is not started by torch.distributed.run)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="default workload: skip the config.also measurements")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe: planner handles taking the frames in turn (0: the workload's)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
+    a = ap.parse_args()
+    d_steps, d_warm = DEFAULT_STEPS.get(a.workload, (5, 2))
+    a.steps = d_steps if a.steps is None else a.steps
+    a.warmup = d_warm if a.warmup is None else a.warmup
+    if a.workload == "c5pipe":
+        # one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run one
+        # after the other; read by the HIP runtime when it initialises (nothing has touched the GPU yet)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+    cx = Ctx()
+    cx.rank = int(os.environ.get("RANK", "0"))
+    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cx.gpus = a.gpus
+    # Decided before anything touches a GPU: started by torch.distributed.run (WORLD_SIZE == N) -> one process per GPU;
+    # otherwise ONE process drives all N GPUs through the library's multi-device handle (no torch is imported at all).
+    cx.inlib = a.inlib or (cx.world == 1 and a.gpus > 1)
+    if cx.inlib and cx.world > 1:
+        raise SystemExit("--inlib is a single-process mode: start it without torch.distributed.run")
+    if not cx.inlib and cx.world != a.gpus:
+        raise SystemExit("--gpus %d under torch.distributed.run needs --nproc-per-node %d (WORLD_SIZE is %d)" % (a.gpus, a.gpus, cx.world))
+
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd.distributed import ShardedPlanner
+
+    with open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")) as f:
+        cx.WL = json.load(f)
+
+    cx.torch = cx.dist = cx.sp = None
+    # Bring-up aid for 1-GPU boxes (never set by the driver): FXJPS_BENCH_BACKEND=gloo runs every rank on
+    # device 0 with a host-side broadcast, to exercise the multi-rank code path without a second GPU;
+    # FXJPS_BENCH_ONE_DEVICE=1 gives the in-library handle N contexts on device 0 (everything but the collective).
+    backend = os.environ.get("FXJPS_BENCH_BACKEND", "nccl")
+    cx.dev_index = 0 if backend == "gloo" else local_rank
+    if cx.world > 1:
+        import torch
+        import torch.distributed as dist
+        cx.torch, cx.dist = torch, dist
+        torch.cuda.set_device(cx.dev_index)
+        dist.init_process_group(backend, rank=cx.rank, world_size=cx.world)  # "nccl" is RCCL on ROCm
+        cx.tdev = "cpu" if backend == "gloo" else "cuda:%d" % cx.dev_index
+
+    if cx.inlib:
+        devs = [0] * a.gpus if os.environ.get("FXJPS_BENCH_ONE_DEVICE") else list(range(a.gpus))
+    else:
+        devs = [cx.dev_index]
+    cx.planner = fx.Planner(devs)
+    if cx.world > 1:
+        cx.sp = ShardedPlanner(cx.planner, device=cx.tdev)
+
+    def sync():
+        if cx.world > 1:
+            cx.torch.cuda.synchronize()
+            if backend == "nccl":
+                cx.dist.barrier(device_ids=[cx.dev_index])
+            else:
+                cx.dist.barrier()
+    cx.sync = sync
+
+    m = measure(cx, a.workload, a.steps, a.warmup, a.frames_in_flight)
+
+    # ---- the other BASELINE workloads, behind the headline's timed region (default invocation only)
+    also = {}
+    if a.workload == "c2" and not a.no_also:
+        def brief(r, extra=()):
+            d = {"value": r["value"], "unit": "plans/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"], "kernel_ms": r["kernel_ms"],
+                 "frac": r["frac"], "achieved_GBps": r["achieved"], "queries_per_step": r["total_q"], "scaling": "strong" if r["strong"] else "weak"}
+            for k in extra:
+                d[k] = r[k]
+            return d
+        if a.gpus == 1:
+            r = measure(cx, "c4shard", 2, 1)
+            if r:
+                also["c4shard"] = brief(r)
+        else:
+            r = measure(cx, "c4", 2, 1)  # the 1 M queries of BASELINE config 4 split N ways: the strong-scaling workload
+            if r:
+                also["c4"] = brief(r, ("kernel_ms_per_device",))
+
+    if cx.rank == 0:
+        ci = cx.planner.comm_info()
+        if cx.world > 1:
+            rccl_ranks = cx.world if backend == "nccl" else 0
+            collective = "torch.distributed %s broadcast of the grid, %d ranks" % ("nccl (RCCL)" if backend == "nccl" else backend, cx.world)
+        else:
+            rccl_ranks = ci["rccl_ranks"]
+            collective = ("ncclBroadcast of the grid inside the library, ncclCommCount = %d" % rccl_ranks) if rccl_ranks else \
+                         ("none (one device)" if ci["contexts"] == 1 else "none: %d contexts share %d device(s), device-to-device copies" % (ci["contexts"], ci["devices"]))
         traffic = None  # HBM bytes per launch from the committed PMC passes, only if they were taken on this very source
         tnote = "no PMC pass of this workload on this build committed"
         try:
@@ -225,55 +323,83 @@ def main():
                 tnote = "rocprofv3 FETCH_SIZE+WRITE_SIZE per launch, calibrated (profiles/hbm_traffic.json)"
         except (OSError, KeyError, ValueError):
             pass
+        wl = m["wl"]
         out = {
-            "metric": "start->goal plans/sec on %dx%d grid" % (W, H),
-            "value": value,
+            "metric": "start->goal plans/sec on %dx%d grid" % (m["W"], m["H"]),
+            "value": m["value"],
             "unit": "plans/s",
-            "n_gpus": n_units,
+            "n_gpus": a.gpus,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
+            "scaling": "strong" if m["strong"] else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: %s" % (a.workload, wl["describe"]),
-                       "queries_per_step": total_q, "queries_on_rank0": n_local, "grid": [W, H], "hchoice": hchoice,
-                       "reachable_rank0": int((status > 0).sum()), "retried_on_large_scratch": int(retried),
-                       "parallelism": ("one process, fxjps_create(n_dev=%d)" % n_units) if a.inlib else "queries sharded x%d, one process per GPU" % n_units},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+            "config": {"workload": "%s: %s" % (a.workload, m["describe"]),
+                       "queries_per_step": m["total_q"], "queries_on_rank0": m["n_local"], "grid": [m["W"], m["H"]], "hchoice": m["hchoice"],
+                       "reachable_rank0": int((m["status"] > 0).sum()), "retried_on_large_scratch": m["retried"],
+                       "parallelism": ("one process, fxjps_create(n_dev=%d)" % a.gpus) if cx.inlib else "queries sharded x%d, one process per GPU" % a.gpus,
+                       "rccl_ranks": rccl_ranks, "collective": collective, "contexts": ci["contexts"] if cx.world == 1 else cx.world,
+                       "kernel_ms_per_device": m["kernel_ms_per_device"], "resident_wavefronts": m["waves"], "wavefronts_cut_by_memory": m["waves_short"]},
+            "roofline": {"bound": "hbm", "achieved": m["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": m["frac"], "traffic": traffic,
                          # (the instantiation rocprofv3 lists: heuristic, read-set recording, table indexed by the cell)
-                         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and a.workload not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": algo,
+                         "kernel": m["kernel"],
+                         "kernel_ms": m["kernel_ms"], "algorithmic_bytes_per_launch": m["algo"],
                          "algorithmic_bytes_source": wl.get("algorithmic_bytes_source", "oracle literal mode, all queries (tools/algo_bytes.py)"),
                          "note": "graph search bound by scattered-request rate and instruction issue, not by bytes (DESIGN.md section 4); traffic: " + tnote},
         }
-        if streaming:
-            out["config"].update({"frames_per_s": a.steps / elapsed, "target_frames_per_s": 60,
-                                  "cells_sent_per_frame": int(len(frames[0][1])),
-                                  "results_reused_per_frame": reused / a.steps})
-            if pipe is not None:
-                out["config"].update({"frames_in_flight": int(wl["frames_in_flight"]), "frame_latency_ms": frame_latency_ms,
-                                      "parallelism": "%d planner handles on one GPU take the frames in turn" % int(wl["frames_in_flight"])})
+        if m["streaming"]:
+            out["config"].update({"frames_per_s": m["frames_per_s"], "target_frames_per_s": 60,
+                                  "cells_sent_per_frame": m["cells_sent_per_frame"],
+                                  "results_reused_per_frame": m["results_reused_per_frame"]})
+            if "latency_ms" in m:
+                out["config"].update({"frames_in_flight": m["frames_in_flight"], "planner_handles": m["frames_in_flight"],
+                                      "frame_latency_ms": m["latency_ms"]["mean"], "submit_to_paths_latency_ms": m["latency_ms"],
+                                      "parallelism": "%d planner handles on one GPU take the frames in turn" % m["frames_in_flight"]})
                 out["roofline"]["note"] = "frames overlap: kernel_ms is the frame period; " + out["roofline"]["note"]
-        if world == 1 and not a.inlib and not a.no_cpu_baseline:
+        if a.workload == "c2" and not a.no_also and a.gpus == 1 and cx.world == 1:
+            # config 5 with frames in flight, in a child process of its own (its eight handles want their own hardware
+            # queues -- an environment variable the HIP runtime reads when it starts -- and their own memory)
+            cx.planner.close()
+            cx.planner = None
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c5pipe", "--steps", "64", "--warmup", "16",
+                                    "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and line:
+                    j = json.loads(line[-1])
+                    also["c5pipe"] = {"value": j["config"]["frames_per_s"], "unit": "frames/s", "target": 60, "steps": j["steps"],
+                                      "ms_per_step": j["ms_per_step"], "kernel_ms": j["roofline"]["kernel_ms"], "frac": j["roofline"]["frac"],
+                                      "planner_handles": j["config"]["planner_handles"],
+                                      "submit_to_paths_latency_ms": j["config"]["submit_to_paths_latency_ms"],
+                                      "plans_per_s": j["value"]}
+                else:
+                    also["c5pipe"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+                also["c5pipe"] = {"error": repr(e)[:300]}
+        if also:
+            out["config"]["also"] = also
+        if cx.world == 1 and not cx.inlib and not a.no_cpu_baseline:
             from oracle import oracle  # checker used as the CPU baseline ("port"), never by the planner
-            ns = min(a.cpu_sample or wl.get("cpu_sample", nq), n_local)
+            ns = min(a.cpu_sample or wl.get("cpu_sample", m["wl"]["nq"]), m["n_local"])
             cores = min(os.cpu_count() or 1, 256)
-            g_now = g if pipe is not None else (planner.get_grid() if streaming else occ)
+            nth = min(cores, wl.get("cpu_threads", cores))
+            g_now = m["grid_now"] if m["grid_now"] is not None else m["occ"]  # (streaming: the grid after the last frame)
             tc = time.perf_counter()
-            _, ol, _, _ = oracle.plan_batch(g_now, starts[:ns], goals[:ns], hchoice, literal=False, max_len=mpl, nthreads=min(cores, wl.get("cpu_threads", cores)))
+            _, ol, _, _ = oracle.plan_batch(g_now, m["starts"][:ns], m["goals"][:ns], m["hchoice"], literal=False, max_len=m["mpl"], nthreads=nth)
             dt = time.perf_counter() - tc
-            assert np.array_equal(ol, status[:ns])
-            out["cpu_baseline"] = {"value": ns / dt, "unit": "plans/s", "cores": min(cores, wl.get("cpu_threads", cores)), "kind": "port",
+            assert np.array_equal(ol, m["status"][:ns])
+            out["cpu_baseline"] = {"value": ns / dt, "unit": "plans/s", "cores": nth, "kind": "port",
                                    "sample": "first %d queries of the same batch, oracle/jps_oracle.c (-O2), "
-                                             "%d pthreads, %.1f s" % (ns, min(cores, wl.get("cpu_threads", cores)), dt)}
+                                             "%d pthreads, %.1f s" % (ns, nth, dt)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-    planner.close()
+    if cx.world > 1:
+        cx.dist.destroy_process_group()
+    if cx.planner is not None:
+        cx.planner.close()
 
 
 if __name__ == "__main__":

@@ -8,8 +8,9 @@ roofline.achieved.  Deterministic: depends only on the seeds.
     python tools/algo_bytes.py [c2 c2h1 c4shard c3 c5 c5low]     # default: all; c4 is derived from c4shard
 
 c3 counts a 2 000-query literal sample and extrapolates (x 50) -- the oracle needs ~0.5 M pops per query there; c4 is
-8 x the literal count of its first 125 000 queries; c5 / c5low hold one literal count per frame for the first 40
-frames of the toggle stream.  Meant for a many-core host (the GPU box: ~5 min on 256 threads).
+8 x the literal count of its first 125 000 queries; c5 holds one literal count per frame for the first 616 frames of
+the toggle stream (16 warm-up frames + the 600 frames SURVEY 8d prescribes; c5pipe is the same stream), c5low / c5local
+for the first 40.  Meant for a many-core host (the GPU box: ~5 min on 256 threads, c5 alone ~10 min).
 """
 import json, os, sys, time
 import numpy as np
@@ -30,7 +31,7 @@ WORKLOADS = {
                describe="BASELINE config 4: 1024x1024 grid (seed 1), 1000000 queries (qseed 1) split over the GPUs in contiguous shards, hchoice=2"),
     "c3": dict(W=4096, H=4096, grid_seed=2, p=0.20, qseed=2, hchoice=2, max_path_len=4096, nq=100000, sample=2000, cpu_sample=512, cpu_threads=64,
                describe="BASELINE config 3: 4096x4096 grid, 20% obstacles (seed 2), 100000 queries (qseed 2), hchoice=2"),
-    "c5": dict(C2, qseed=5, nq=1000, max_path_len=2048, toggle_frac=0.05, toggle_seed=5, frames=40,
+    "c5": dict(C2, qseed=5, nq=1000, max_path_len=2048, toggle_frac=0.05, toggle_seed=5, frames=616,  # 16 warm-up + the 600 frames of SURVEY 8d
                describe="BASELINE config 5, streaming replan: 1024x1024 grid (seed 1), per frame floor(0.05*W*H) occupied cells freed and as many "
                         "free cells occupied (10% of the cells toggled, SURVEY 8d splitmix stream, seed 5), 1000 persistent queries (qseed 5) "
                         "replanned every frame, target 60 frames/s"),
@@ -75,6 +76,8 @@ def main():
                 c, ln = count(occ, s, g, w["hchoice"], w["max_path_len"])
                 per.append(c["algorithmic_bytes"])
                 reach.append(int((ln > 0).sum()))
+                if fr % 20 == 19:
+                    print("%s frame %d of %d, %.0f s" % (name, fr + 1, w["frames"], time.time() - t), flush=True)
             rec.update(algorithmic_bytes_per_frame=per, reachable_per_frame=reach, algorithmic_bytes=int(np.mean(per)),
                        algorithmic_bytes_source="oracle literal mode, all 1000 queries of each of the first %d frames" % w["frames"])
         else:
