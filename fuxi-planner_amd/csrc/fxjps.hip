@@ -1489,6 +1489,71 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
     return FXJPS_OK;
 }
 
+int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t near_max, double delta0, const uint64_t* keys_f,
+                            const uint32_t* keys_x, int64_t nkeys, const uint32_t* step_pops, const uint32_t* step_off, int32_t nsteps,
+                            uint64_t* out_f, uint32_t* out_x, uint32_t* out_slot, uint32_t* out_k, uint32_t* out_info) {
+    if (!h || !keys_f || !keys_x || !step_pops || !step_off || !out_f || !out_x || !out_slot || !out_k || !out_info || nkeys < 0 ||
+        nkeys > (1 << 24) || nsteps < 0 || far_cap < 64 || far_cap > (1 << 24) || (far_cap & 7) || near_max < 1 || !(delta0 > 0.0))
+        return fail(h, FXJPS_E_ARG, "bad selftest arguments");
+    if (step_off[0] != 0u || (int64_t)step_off[nsteps] != nkeys) return fail(h, FXJPS_E_ARG, "step offsets do not cover the keys");
+    for (int32_t i = 0; i < nsteps; i++)
+        if (step_off[i + 1] < step_off[i] || step_off[i + 1] - step_off[i] > 64u) return fail(h, FXJPS_E_ARG, "a step pushes at most 64 keys");
+    if (banded)  // (the ring reads the cell info of an entry from the map again: the test map is 64 x 64)
+        for (int64_t i = 0; i < nkeys; i++)
+            if ((keys_x[i] >> 17) >= 64u || ((keys_x[i] >> 4) & 0x1FFFu) >= 64u) return fail(h, FXJPS_E_ARG, "banded selftest: cells below 64 x 64");
+    DevCtx& d = h->devs[0];
+    HIPCHK(h, hipSetDevice(d.dev));
+    const size_t nk = (size_t)std::max<int64_t>(nkeys, 1), ns = (size_t)std::max(nsteps, 1);
+    const size_t far_n = (size_t)far_cap + (size_t)far_cap / 8;
+    const size_t ci_n = (size_t)66 * 128;
+    // one allocation: far tier | cell info | keys f | out f | keys x | out x | out slot | step pops | step offsets | out k | info
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_far = take(far_n * sizeof(FarEnt)), o_ci = take(ci_n * 2), o_kf = take(nk * 8), o_of = take(nk * 8), o_kx = take(nk * 4),
+                 o_ox = take(nk * 4), o_os = take(nk * 4), o_sp = take(ns * 4), o_so = take((ns + 1) * 4), o_ok = take(ns * 4), o_in = take(16), o_cn = take(64 * 8);
+    char* buf = nullptr;
+    HIPCHK(h, hipMalloc((void**)&buf, off));
+    hipError_t e = hipMemsetAsync(buf, 0, off, d.stream);
+    if (e == hipSuccess && nkeys > 0) e = hipMemcpyAsync(buf + o_kf, keys_f, (size_t)nkeys * 8, hipMemcpyHostToDevice, d.stream);
+    if (e == hipSuccess && nkeys > 0) e = hipMemcpyAsync(buf + o_kx, keys_x, (size_t)nkeys * 4, hipMemcpyHostToDevice, d.stream);
+    if (e == hipSuccess && nsteps > 0) e = hipMemcpyAsync(buf + o_sp, step_pops, (size_t)nsteps * 4, hipMemcpyHostToDevice, d.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(buf + o_so, step_off, ((size_t)nsteps + 1) * 4, hipMemcpyHostToDevice, d.stream);
+    if (e == hipSuccess) {
+        SearchArgs A{};
+        A.G.ci = reinterpret_cast<const uint16_t*>(buf + o_ci);
+        A.G.NS = 128;
+        A.far = reinterpret_cast<FarEnt*>(buf + o_far);
+        A.far_cap = (uint32_t)far_cap;
+        A.near_max = (uint32_t)near_max;
+        A.banded = banded ? 1u : 0u;
+        A.out_counters = reinterpret_cast<unsigned long long*>(buf + o_cn);  // [2] far refills, [3] direct pops from the far tier
+        auto kf = reinterpret_cast<const unsigned long long*>(buf + o_kf);
+        auto of = reinterpret_cast<unsigned long long*>(buf + o_of);
+        auto kx = reinterpret_cast<const uint32_t*>(buf + o_kx);
+        auto ox = reinterpret_cast<uint32_t*>(buf + o_ox), os = reinterpret_cast<uint32_t*>(buf + o_os), ok = reinterpret_cast<uint32_t*>(buf + o_ok),
+             in = reinterpret_cast<uint32_t*>(buf + o_in);
+        auto sp = reinterpret_cast<const uint32_t*>(buf + o_sp), so = reinterpret_cast<const uint32_t*>(buf + o_so);
+        if (banded)
+            hipLaunchKernelGGL(fx::k_selftest_openlist<true>, dim3(1), dim3(64), 0, d.stream, A, kf, kx, sp, so, (uint32_t)nsteps, delta0, of, ox, os, ok, in, (uint32_t)nkeys);
+        else
+            hipLaunchKernelGGL(fx::k_selftest_openlist<false>, dim3(1), dim3(64), 0, d.stream, A, kf, kx, sp, so, (uint32_t)nsteps, delta0, of, ox, os, ok, in, (uint32_t)nkeys);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && nkeys > 0) e = hipMemcpyAsync(out_f, buf + o_of, (size_t)nkeys * 8, hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess && nkeys > 0) e = hipMemcpyAsync(out_x, buf + o_ox, (size_t)nkeys * 4, hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess && nkeys > 0) e = hipMemcpyAsync(out_slot, buf + o_os, (size_t)nkeys * 4, hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess && nsteps > 0) e = hipMemcpyAsync(out_k, buf + o_ok, (size_t)nsteps * 4, hipMemcpyDeviceToHost, d.stream);
+    unsigned long long cn[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(out_info, buf + o_in, 8, hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cn, buf + o_cn, sizeof(cn), hipMemcpyDeviceToHost, d.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
+    (void)hipFree(buf);
+    out_info[2] = (uint32_t)std::min<unsigned long long>(cn[2], 0xFFFFFFFFull);
+    out_info[3] = (uint32_t)std::min<unsigned long long>(cn[3], 0xFFFFFFFFull);
+    if (e != hipSuccess) return fail(h, FXJPS_E_HIP, "selftest: %s", hipGetErrorString(e));
+    return FXJPS_OK;
+}
+
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf) {
     if (!h || !buf) return FXJPS_E_ARG;
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");

@@ -297,6 +297,24 @@ class Planner(object):
         self._chk(self._L.fxjps_selftest_wavemin(self._h, rounds, seed, C.byref(bad)))
         return bad.value
 
+    def selftest_openlist(self, keys_f, keys_x, step_pops, step_off, banded=False, far_cap=8192, near_max=512, delta0=2.0):
+        """Run a push / pop script through the open list of the search kernel (fxjps_selftest_openlist).
+        -> (popped f bits uint64[n], popped x uint32[n], pushed-entry index uint32[n], pops per step uint32[nsteps],
+        {fail, far_refills, slow_pops})"""
+        kf = np.ascontiguousarray(keys_f, dtype=np.uint64)
+        kx = np.ascontiguousarray(keys_x, dtype=np.uint32)
+        sp = np.ascontiguousarray(step_pops, dtype=np.uint32)
+        so = np.ascontiguousarray(step_off, dtype=np.uint32)
+        n, ns = len(kf), len(sp)
+        of, ox, os_ = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        ok, info = np.zeros(max(ns, 1), np.uint32), np.zeros(4, np.uint32)
+        self._chk(self._L.fxjps_selftest_openlist(self._h, int(bool(banded)), int(far_cap), int(near_max), float(delta0),
+                                                  _lib.ptr(kf, C.c_uint64), _lib.ptr(kx, C.c_uint32), n, _lib.ptr(sp, C.c_uint32),
+                                                  _lib.ptr(so, C.c_uint32), ns, _lib.ptr(of, C.c_uint64), _lib.ptr(ox, C.c_uint32),
+                                                  _lib.ptr(os_, C.c_uint32), _lib.ptr(ok, C.c_uint32), _lib.ptr(info, C.c_uint32)))
+        t = int(info[0])
+        return of[:t], ox[:t], os_[:t], ok[:ns], {"fail": int(info[1]), "far_refills": int(info[2]), "slow_pops": int(info[3])}
+
     def debug_nbmask(self):
         W, H = self.shape
         buf = np.empty((W + 2, H + 2), dtype=np.uint8)

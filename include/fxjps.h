@@ -229,6 +229,20 @@ int fxjps_selftest_sqrt(fxjps_t* h, uint32_t n0, uint32_t n1, double* out);
  * shuffle form and a host reference, on `rounds` rows of 64 pseudo-random values. */
 int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* mismatches);
 
+/* Device self-test of the open list alone: one wavefront runs a script of nsteps steps through the open-list code of
+ * the search kernel (registers / LDS / global-memory tiers; banded != 0: the far band as a ring of f bands) -- step i
+ * pops up to step_pops[i] entries (as many as the register tier holds, at least one while the list is not empty) and
+ * then pushes the keys [step_off[i], step_off[i+1]) (at most 64; key = (keys_f, keys_x): f as raw bits, packed
+ * x:13|y:13|direction:4) -- and then pops until the list is empty.  out_f / out_x / out_slot (nkeys each) receive the
+ * popped keys and the index of the pushed entry each one was, in pop order; out_k[i] the number of pops of step i;
+ * out_info[0] the total popped, out_info[1] a failure code (0: none, 1 / 2: a far-tier region was full, 3: more pops
+ * than pushes), out_info[2] the refills from the global-memory tier, out_info[3] the pops taken straight from it (more
+ * than 256 entries with one and the same full key); out_info holds 4 values.  far_cap / near_max size the global-memory tier as the planner's scratch configuration would (tests
+ * make them tiny); delta0 is the first refill width.  The host checks the pops against a binary heap. */
+int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t near_max, double delta0, const uint64_t* keys_f,
+                            const uint32_t* keys_x, int64_t nkeys, const uint32_t* step_pops, const uint32_t* step_off, int32_t nsteps,
+                            uint64_t* out_f, uint32_t* out_x, uint32_t* out_slot, uint32_t* out_k, uint32_t* out_info);
+
 /* Copy the derived device maps back for inspection (tests): the padded
  * (W+2)x(H+2) neighbour-mask bytes.  buf must hold (W+2)*(H+2) bytes. */
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);

@@ -61,6 +61,108 @@ def test_wavefront_minimum(planner):
     assert planner.selftest_wavemin(1000, 99) == 0
 
 
+def _openlist_script(planner, keys_f, keys_x, step_pops, step_off, expect_fail=False, **cfg):
+    """Run the script on the device, replay it on a binary heap: every pop is the minimum, every entry comes out once."""
+    import heapq
+    kf = np.ascontiguousarray(keys_f, dtype=np.float64).view(np.uint64)
+    kx = np.ascontiguousarray(keys_x, dtype=np.uint32)
+    of, ox, os_, ok, info = planner.selftest_openlist(kf, kx, step_pops, step_off, **cfg)
+    heap, pos, used = [], 0, np.zeros(len(kf), dtype=bool)
+
+    def pop_check():
+        f, x = heapq.heappop(heap)
+        assert (int(of[pos]), int(ox[pos])) == (f, x), (pos, hex(int(of[pos])), hex(f), hex(int(ox[pos])), hex(x))
+        sl = int(os_[pos])
+        assert int(kf[sl]) == f and int(kx[sl]) == x and not used[sl], (pos, sl)  # the payload follows its key, once
+        used[sl] = True
+
+    for i in range(len(step_pops)):
+        if info["fail"] and pos >= len(of):  # (the script stopped here: a far-tier region was full)
+            break
+        assert int(ok[i]) <= int(step_pops[i]) and (int(ok[i]) >= 1 or not heap or int(step_pops[i]) == 0), (i, int(ok[i]))
+        for _ in range(int(ok[i])):
+            pop_check()
+            pos += 1
+        for j in range(int(step_off[i]), int(step_off[i + 1])):
+            heapq.heappush(heap, (int(kf[j]), int(kx[j])))
+    if expect_fail:
+        assert info["fail"] in (1, 2), info
+        return info
+    assert info["fail"] == 0, info
+    while pos < len(of):
+        pop_check()
+        pos += 1
+    assert not heap and used.all() and len(of) == len(kf)
+    return info
+
+
+def _script(rng, n, key_fn, max_pop=16, max_push=24, bursts=True):
+    pops, off, kf, kx = [], [0], [], []
+    t = 0
+    while len(kf) < n:
+        m = int(rng.integers(0, max_push + 1))
+        if bursts and rng.random() < 0.02:
+            m = 64
+        m = min(m, n - len(kf))
+        f, x = key_fn(t, m)
+        kf.extend(f)
+        kx.extend(x)
+        off.append(len(kf))
+        pops.append(int(rng.integers(0, max_pop + 1)))
+        t += 1
+    return np.array(kf, np.float64), np.array(kx, np.uint32), np.array(pops, np.uint32), np.array(off, np.uint32)
+
+
+def test_open_list_alone(planner):
+    """The three-tier open list of the search kernel, driven directly (fxjps_selftest_openlist): A*-like key streams,
+    integer keys with hundreds of ties per level, adversarial orders, far tiers of a few hundred entries -- and what no
+    map produces: thousands of entries with one and the same full key, which only the direct pop from the global tier
+    can hand out (`slow_pops` asserted), with the lazily deleted near band in front of it."""
+    rng = np.random.default_rng(31)
+
+    def xy(m, lim=8192):
+        return ((rng.integers(0, lim, m) << 17) | (rng.integers(0, lim, m) << 4) | rng.integers(0, 11, m)).astype(np.uint32)
+
+    # 1. an A* frontier: keys a little above a slowly rising floor, more pushes than pops, then the drain
+    def astar(t, m):
+        return 100.0 + 0.01 * t + rng.random(m) * rng.choice([0.5, 5.0, 50.0]), xy(m)
+    for cfg in ({}, {"far_cap": 2048, "near_max": 48}, {"far_cap": 1024, "near_max": 8, "delta0": 0.05}):
+        info = _openlist_script(planner, *_script(rng, 60000, astar), **cfg)
+        assert info["far_refills"] > 50, info
+    # 2. octile-like integer keys: few levels, hundreds of entries each (refills slice one level on (x, y))
+    def octile(t, m):
+        return (1000 + 10 * (t // 200) + 4 * rng.integers(0, 6, m)).astype(np.float64), xy(m)
+    for cfg in ({"delta0": 20.0}, {"delta0": 20.0, "far_cap": 4096, "near_max": 32}):
+        _openlist_script(planner, *_script(rng, 50000, octile), **cfg)
+    # 3. no order at all, and keys far below everything popped so far
+    def wild(t, m):
+        return np.abs(rng.normal(0.0, 1.0, m)) * 10.0 ** rng.integers(-3, 6), xy(m)
+    _openlist_script(planner, *_script(rng, 40000, wild, max_pop=40), far_cap=8192, near_max=64)
+    # 4. one and the same full key, thousands of times, among others: the tiers cannot split them
+    def flood(t, m):
+        f = 50.0 + rng.random(m)
+        x = xy(m)
+        same = rng.random(m) < 0.7
+        f[same] = 50.5
+        x[same] = (77 << 17) | (99 << 4) | 3
+        return f, x
+    info = _openlist_script(planner, *_script(rng, 20000, flood, max_pop=6), far_cap=32768, near_max=128)
+    assert info["slow_pops"] > 1000, info
+    info = _openlist_script(planner, *_script(rng, 6000, lambda t, m: (np.full(m, 7.0), np.full(m, 5 << 4, np.uint32)), max_pop=3))
+    assert info["slow_pops"] > 1000, info
+    # 5. the far band as a ring of f bands (large grids): set-up, whole bands into M, oversized bands, the last region
+    #    dealt out again; cells below 64 x 64 (the ring reads cell infos from the map)
+    def wide(t, m):
+        return 10.0 + 0.05 * t + rng.random(m) * rng.choice([1.0, 20.0, 300.0]), xy(m, 64)
+    for cfg in ({"far_cap": 65536, "near_max": 128}, {"far_cap": 32768, "near_max": 32, "delta0": 0.5}):
+        info = _openlist_script(planner, *_script(rng, 80000, wide, max_pop=12), banded=True, **cfg)
+        assert info["far_refills"] > 100, info
+    # ... and regions that overflow: the failure is reported (the search re-runs such a query on the large pool),
+    # what was popped until then is right
+    _openlist_script(planner, *_script(rng, 60000, wide, max_pop=4), banded=True, far_cap=4096, near_max=16, expect_fail=True)
+    _openlist_script(planner, *_script(rng, 30000, astar, max_pop=2), far_cap=256, near_max=16, expect_fail=True)
+
+
 # ------------------------------------------------------------------ golden vectors from jps1.py
 def test_known_answers_through_the_jps1_shim(planner):
     """The drop-in module: same return tuple, same printed cost, `path1[0] is 0` for no path."""
