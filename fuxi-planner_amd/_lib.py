@@ -16,7 +16,7 @@ BACKEND_HIP = 1
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
            "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask",
-           "fxjps_waypoint_st", "fxjps_waypoint_ccst")
+           "fxjps_waypoint_st", "fxjps_waypoint_ccst", "fxjps_waypoint_ccst_batch", "fxjps_waypoint_st_batch")
 
 
 class Timing(C.Structure):
@@ -122,6 +122,12 @@ def load():
                                           p_u64, p_u32, p_u32, p_u32, p_u32]
     L.fxjps_debug_read_nbmask.restype = C.c_int
     L.fxjps_debug_read_nbmask.argtypes = [vp, p_u8]
+    L.fxjps_waypoint_ccst_batch.restype = C.c_int
+    L.fxjps_waypoint_ccst_batch.argtypes = [vp, C.c_int64, p_i64, p_i32, C.c_double, p_f64, p_f64, p_f64, p_i32, p_f64, p_f64, p_i32, p_i32,
+                                            C.c_int64]
+    L.fxjps_waypoint_st_batch.restype = C.c_int
+    L.fxjps_waypoint_st_batch.argtypes = [vp, C.c_int64, p_i64, p_i32, p_i32, C.c_double, p_f64, p_f64, p_f64, p_i32, C.c_double, C.c_double,
+                                          p_f64, p_i32, p_f64, p_i32, p_f64, p_f64, C.c_int32]
     bind_host(L)
     _lib = L
     return L

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fxjps.h"
@@ -129,6 +130,10 @@ struct DevCtx {
     int mode = 0;                 // 0 plain batch, 1 search everything and record read sets, 2 the same for h_sel only
     int64_t nrun = 0;             // queries handed to the search kernel
     DBuf<uint8_t> d_raw, d_img;
+    // waypoint selection over a batch (fxjps_waypoint_ccst_batch)
+    DBuf<double> d_wp_in, d_wp_out;
+    DBuf<int32_t> d_wp_eo, d_wp_nkept, d_wp_kept, d_wp_cells, d_wp_len;
+    DBuf<long long> d_wp_off;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val;
     // pinned staging of a cell-update list: the caller's arrays are copied here before the asynchronous H2D copy, so
@@ -844,6 +849,14 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_qread.release();
         d.d_raw.release();
         d.d_img.release();
+        d.d_wp_in.release();
+        d.d_wp_out.release();
+        d.d_wp_eo.release();
+        d.d_wp_nkept.release();
+        d.d_wp_kept.release();
+        d.d_wp_cells.release();
+        d.d_wp_len.release();
+        d.d_wp_off.release();
         d.d_upd_xy.release();
         d.d_upd_val.release();
         d.h_len.release();
@@ -1370,6 +1383,167 @@ int fxjps_last_timing_device(fxjps_t* h, int32_t ctx, int32_t* out_device, int64
     if (out_nq) *out_nq = d.nq;
     if (out_kernel_ms) *out_kernel_ms = d.kernel_ms;
     if (out_waves) *out_waves = d.waves_used;
+    return FXJPS_OK;
+}
+
+// ------------------------------------------------------------------ waypoint selection over a batch
+int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, const int32_t* cells_xy, double reso, const double* origin,
+                              const double* pos, const double* goal, const int32_t* end_occu, double* out_wp, double* out_goal,
+                              int32_t* out_n_kept, int32_t* out_kept_cells, int64_t kept_capacity) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "fxjps_waypoint_ccst_batch before fxjps_set_grid");
+    if (nq < 0 || !origin || (nq > 0 && (!pos || !goal || !out_wp))) return fail(h, FXJPS_E_ARG, "bad waypoint arguments");
+    if ((cells_xy != nullptr) != (offsets != nullptr)) return fail(h, FXJPS_E_ARG, "offsets and cells_xy go together");
+    if (!cells_xy && nq != h->last_nq) return fail(h, FXJPS_E_ARG, "the last batch had %lld queries, not %lld", (long long)h->last_nq, (long long)nq);
+    if (h->maps_stale) {  // (the grid is what the line test reads; deferred updates are queued on the same streams anyway)
+        int rc = update_cells_async(h, nullptr, nullptr, 0, true);
+        if (rc) return rc;
+    }
+    if (nq == 0) return FXJPS_OK;
+    // the paths: the caller's CSR (device 0 takes all of them), or the last batch's, resident shard by shard
+    struct Part {
+        DevCtx* d;
+        int64_t q0, n;
+        const long long* d_off;
+        const int32_t *d_cells, *d_len;
+        long long total;
+    };
+    std::vector<Part> parts;
+    int64_t kept_base = 0;
+    std::vector<int64_t> kept_at;
+    if (cells_xy) {
+        for (int64_t q = 0; q < nq; q++)
+            if (offsets[q + 1] < offsets[q]) return fail(h, FXJPS_E_ARG, "offsets must ascend");
+        if (offsets[0] != 0) return fail(h, FXJPS_E_ARG, "offsets[0] must be 0");
+        for (int64_t i = 0; i < 2 * offsets[nq]; i++)
+            if (cells_xy[i] < 0) return fail(h, FXJPS_E_ARG, "negative cell");
+        DevCtx& d = h->devs[0];
+        HIPCHK(h, hipSetDevice(d.dev));
+        const long long total = offsets[nq];
+        HIPCHK(h, d.d_wp_off.ensure((size_t)nq + 1));
+        HIPCHK(h, d.d_wp_len.ensure((size_t)nq));
+        HIPCHK(h, d.d_wp_cells.ensure((size_t)std::max<long long>(total, 1) * 2));
+        std::vector<int32_t> len((size_t)nq);
+        for (int64_t q = 0; q < nq; q++) len[(size_t)q] = (int32_t)std::min<int64_t>(offsets[q + 1] - offsets[q], 0x7FFFFFFF);
+        static_assert(sizeof(long long) == sizeof(int64_t), "offsets are copied as they are");
+        HIPCHK(h, hipMemcpyAsync(d.d_wp_off.p, offsets, ((size_t)nq + 1) * sizeof(long long), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipMemcpyAsync(d.d_wp_len.p, len.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        if (total > 0) HIPCHK(h, hipMemcpyAsync(d.d_wp_cells.p, cells_xy, (size_t)total * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipStreamSynchronize(d.stream));  // (`len` is pageable host memory)
+        parts.push_back(Part{&d, 0, nq, d.d_wp_off.p, d.d_wp_cells.p, d.d_wp_len.p, total});
+        kept_at.push_back(0);
+        kept_base = total;
+    } else {
+        for (auto& d : h->devs) {
+            if (d.nq == 0) continue;
+            const long long total = d.h_offsets.p[d.nq];
+            parts.push_back(Part{&d, d.q0, d.nq, d.d_offsets.p, d.d_cells.p, d.d_len.p, total});
+            kept_at.push_back(kept_base);
+            kept_base += total;
+        }
+    }
+    if (out_kept_cells && kept_capacity < kept_base)
+        return fail(h, FXJPS_E_ARG, "out_kept_cells holds %lld pairs, the paths have %lld", (long long)kept_capacity, (long long)kept_base);
+    int rc = FXJPS_OK;
+    for (auto& P : parts) {  // queue every device, then collect
+        DevCtx& d = *P.d;
+        HIPCHK(h, hipSetDevice(d.dev));
+        const size_t n = (size_t)P.n;
+        HIPCHK(h, d.d_wp_in.ensure(n * 6));
+        HIPCHK(h, d.d_wp_out.ensure(n * 6));
+        HIPCHK(h, d.d_wp_eo.ensure(n));
+        HIPCHK(h, d.d_wp_nkept.ensure(n));
+        HIPCHK(h, d.d_wp_kept.ensure((size_t)std::max<long long>(P.total, 1) * 2));
+        HIPCHK(h, hipMemcpyAsync(d.d_wp_in.p, pos + 3 * P.q0, n * 3 * sizeof(double), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipMemcpyAsync(d.d_wp_in.p + n * 3, goal + 3 * P.q0, n * 3 * sizeof(double), hipMemcpyHostToDevice, d.stream));
+        if (end_occu) HIPCHK(h, hipMemcpyAsync(d.d_wp_eo.p, end_occu + P.q0, n * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        fx::WaypointArgs A;
+        A.occ = d.occ.p;
+        A.W = d.W;
+        A.H = d.H;
+        A.cells = P.d_cells;
+        A.offsets = P.d_off;
+        A.len = P.d_len;
+        A.nq = (long long)P.n;
+        A.reso = reso;
+        A.ox = origin[0];
+        A.oy = origin[1];
+        A.pos = d.d_wp_in.p;
+        A.goal = d.d_wp_in.p + n * 3;
+        A.end_occu = end_occu ? d.d_wp_eo.p : nullptr;
+        A.out_wp = d.d_wp_out.p;
+        A.out_goal = d.d_wp_out.p + n * 3;
+        A.out_nkept = d.d_wp_nkept.p;
+        A.kept = d.d_wp_kept.p;
+        hipLaunchKernelGGL(fx::k_waypoint_ccst, dim3((unsigned)((P.n + 3) / 4)), dim3(256), 0, d.stream, A);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(out_wp + 3 * P.q0, d.d_wp_out.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+        if (out_goal) HIPCHK(h, hipMemcpyAsync(out_goal + 3 * P.q0, d.d_wp_out.p + n * 3, n * 3 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+        if (out_n_kept) HIPCHK(h, hipMemcpyAsync(out_n_kept + P.q0, d.d_wp_nkept.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+        if (out_kept_cells && P.total > 0)
+            HIPCHK(h, hipMemcpyAsync(out_kept_cells + 2 * kept_at[(size_t)(&P - parts.data())], d.d_wp_kept.p, (size_t)P.total * 2 * sizeof(int32_t),
+                                     hipMemcpyDeviceToHost, d.stream));
+    }
+    for (auto& P : parts) {
+        if (hipSetDevice(P.d->dev) != hipSuccess || hipStreamSynchronize(P.d->stream) != hipSuccess) rc = fail(h, FXJPS_E_HIP, "waypoint kernel failed");
+    }
+    return rc;
+}
+
+int fxjps_waypoint_st_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, const int32_t* cells_xy, const int32_t* map_start, double reso,
+                            const double* origin, const double* pos, const double* goal, const int32_t* end_occu, double dis_wp_tre,
+                            double ang_wp_tre, const double* prev_wp, const int32_t* prev_dim, double* out_wp, int32_t* out_dim,
+                            double* out_goal, double* out_ang_wp, int32_t nthreads) {
+    if (!h) return FXJPS_E_ARG;
+    if (nq < 0 || !origin || (nq > 0 && (!map_start || !pos || !goal || !out_wp || !out_dim || !out_goal || !out_ang_wp)))
+        return fail(h, FXJPS_E_ARG, "bad waypoint arguments");
+    if ((cells_xy != nullptr) != (offsets != nullptr)) return fail(h, FXJPS_E_ARG, "offsets and cells_xy go together");
+    if ((prev_wp != nullptr) != (prev_dim != nullptr)) return fail(h, FXJPS_E_ARG, "prev_wp and prev_dim go together");
+    if (!cells_xy && nq != h->last_nq) return fail(h, FXJPS_E_ARG, "the last batch had %lld queries, not %lld", (long long)h->last_nq, (long long)nq);
+    // path q: its cells and their number (the last batch's paths are in the handle's pinned host buffers, shard by shard)
+    auto path_of = [&](int64_t q, const int32_t** c) -> int64_t {
+        if (cells_xy) {
+            *c = cells_xy + 2 * offsets[q];
+            return offsets[q + 1] - offsets[q];
+        }
+        for (auto& d : h->devs)
+            if (q >= d.q0 && q < d.q0 + d.nq) {
+                const int64_t i = q - d.q0;
+                *c = d.h_cells.p + 2 * d.h_offsets.p[i];
+                return d.h_offsets.p[i + 1] - d.h_offsets.p[i];
+            }
+        *c = nullptr;
+        return 0;
+    };
+    int nt = std::max(1, std::min<int>(nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency(), 256));
+    nt = (int)std::min<int64_t>(nt, std::max<int64_t>(nq / 256, 1));
+    std::vector<int> bad((size_t)nt, 0);
+    auto work = [&](int t) {
+        for (int64_t q = nq * t / nt; q < nq * (t + 1) / nt; q++) {
+            const int32_t* c = nullptr;
+            const int64_t n = path_of(q, &c);
+            if (n <= 0) {  // no path: wp = global_goal    global_planner_st.py:287-290
+                for (int k = 0; k < 3; k++) out_wp[3 * q + k] = out_goal[3 * q + k] = goal[3 * q + k];
+                out_dim[q] = 3;
+                out_ang_wp[q] = 0.0;
+                continue;
+            }
+            const bool hp = prev_wp && (prev_dim[q] == 2 || prev_dim[q] == 3);
+            if (fxjps_waypoint_st(c, (int32_t)n, map_start + 2 * q, reso, origin, pos + 3 * q, goal + 3 * q, end_occu ? end_occu[q] : 0, dis_wp_tre,
+                                  ang_wp_tre, hp ? prev_wp + 3 * q : nullptr, hp ? prev_dim[q] : 0, out_wp + 3 * q, out_dim + q, out_goal + 3 * q,
+                                  out_ang_wp + q) != FXJPS_OK)
+                bad[(size_t)t] = 1;
+        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+    }
+    for (int b : bad)
+        if (b) return fail(h, FXJPS_E_ARG, "fxjps_waypoint_st failed on a path");
     return FXJPS_OK;
 }
 

@@ -80,3 +80,72 @@ def select_ccst(path, mapu, map_reso, map_o, pos, global_goal, end_occu=0, retur
     if return_goal:
         return wp, kept[:nk.value].copy(), gout
     return wp, kept[:nk.value].copy()
+
+
+def _batch_vec(v, n):
+    a = np.asarray(v, dtype=np.float64)
+    if a.ndim == 1:
+        a = np.broadcast_to(a, (n, 3))
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != (n, 3):
+        raise ValueError("expected %d x 3 values" % n)
+    return a
+
+
+def _batch_paths(planner, paths, n_hint):
+    """paths: None (the planner's most recent batch, resident on the device) or (offsets, cells) as plan_batch returns."""
+    if paths is None:
+        return n_hint, None, None
+    off = np.ascontiguousarray(paths[0], dtype=np.int64)
+    cells = np.ascontiguousarray(np.asarray(paths[1], dtype=np.int32).reshape(-1, 2))
+    return len(off) - 1, off, cells
+
+
+def select_ccst_batch(planner, nq, map_reso, map_o, pos, global_goal, end_occu=None, paths=None, return_kept=False):
+    """global_planner_ccst.py:487-544 for every path of a batch, on the device, against the planner's resident grid
+    (fxjps_waypoint_ccst_batch).  paths=None: the paths of the planner's last plan_batch / replan_frame (`nq` of them).
+    pos / global_goal: one (x, y, z) for all, or nq x 3.  -> (wp float64[nq, 3], global_goal float64[nq, 3], n_kept int32[nq])
+    [+ kept cells int32[total, 2], aligned with the offsets of the paths, when return_kept]."""
+    nq, off, cells = _batch_paths(planner, paths, int(nq))
+    o = _vec(map_o, 2)
+    p, g = _batch_vec(pos, nq), _batch_vec(global_goal, nq)
+    eo = None if end_occu is None else np.ascontiguousarray(np.broadcast_to(np.asarray(end_occu, dtype=np.int32), (nq,)))
+    wp, gout, nk = np.zeros((nq, 3)), np.zeros((nq, 3)), np.zeros(nq, dtype=np.int32)
+    kept = None
+    cap = 0
+    if return_kept:
+        if off is None:
+            raise ValueError("return_kept needs the paths (their offsets place the kept cells)")
+        cap = int(off[-1])
+        kept = np.zeros((max(cap, 1), 2), dtype=np.int32)
+    planner._chk(planner._L.fxjps_waypoint_ccst_batch(
+        planner._h, nq, None if off is None else _lib.ptr(off, C.c_int64), None if cells is None else _lib.ptr(cells, C.c_int32),
+        float(map_reso), _lib.ptr(o, C.c_double), _lib.ptr(p, C.c_double), _lib.ptr(g, C.c_double),
+        None if eo is None else _lib.ptr(eo, C.c_int32), _lib.ptr(wp, C.c_double), _lib.ptr(gout, C.c_double), _lib.ptr(nk, C.c_int32),
+        None if kept is None else _lib.ptr(kept, C.c_int32), cap))
+    if return_kept:
+        return wp, gout, nk, kept[:cap]
+    return wp, gout, nk
+
+
+def select_st_batch(planner, nq, map_start, map_reso, map_o, pos, global_goal, end_occu=None, prev_wp=None, prev_dim=None, paths=None,
+                    dis_wp_tre=2.0, ang_wp_tre=math.pi / 4, nthreads=0):
+    """global_planner_st.py:292-327 for every path of a batch, on host threads (fxjps_waypoint_st_batch).
+    -> (wp float64[nq, 3], dim int32[nq] (2 or 3 valid components), global_goal float64[nq, 3], ang_wp float64[nq])"""
+    nq, off, cells = _batch_paths(planner, paths, int(nq))
+    o = _vec(map_o, 2)
+    p, g = _batch_vec(pos, nq), _batch_vec(global_goal, nq)
+    ms = np.ascontiguousarray(np.broadcast_to(np.asarray(map_start, dtype=np.int32), (nq, 2)))
+    eo = None if end_occu is None else np.ascontiguousarray(np.broadcast_to(np.asarray(end_occu, dtype=np.int32), (nq,)))
+    pw = pd = None
+    if prev_wp is not None:
+        pw = np.ascontiguousarray(np.asarray(prev_wp, dtype=np.float64).reshape(nq, 3))
+        pd = np.ascontiguousarray(np.asarray(prev_dim, dtype=np.int32).reshape(nq))
+    wp, gout, dim, ang = np.zeros((nq, 3)), np.zeros((nq, 3)), np.zeros(nq, dtype=np.int32), np.zeros(nq)
+    planner._chk(planner._L.fxjps_waypoint_st_batch(
+        planner._h, nq, None if off is None else _lib.ptr(off, C.c_int64), None if cells is None else _lib.ptr(cells, C.c_int32),
+        _lib.ptr(ms, C.c_int32), float(map_reso), _lib.ptr(o, C.c_double), _lib.ptr(p, C.c_double), _lib.ptr(g, C.c_double),
+        None if eo is None else _lib.ptr(eo, C.c_int32), float(dis_wp_tre), float(ang_wp_tre),
+        None if pw is None else _lib.ptr(pw, C.c_double), None if pd is None else _lib.ptr(pd, C.c_int32),
+        _lib.ptr(wp, C.c_double), _lib.ptr(dim, C.c_int32), _lib.ptr(gout, C.c_double), _lib.ptr(ang, C.c_double), int(nthreads)))
+    return wp, dim, gout, ang

@@ -247,7 +247,8 @@ int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t
  * (W+2)x(H+2) neighbour-mask bytes.  buf must hold (W+2)*(H+2) bytes. */
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
 
-/* ---- Waypoint selection after a plan.  Host functions (no device work, no handle):
+/* ---- Waypoint selection after a plan.  One path per call, host functions (no device work, no handle;
+ * the batch forms below take the grid from the handle and run the ccst pruning on the device):
  * the step the reference's nodes run on the path jps1.method returned.  `cells` are the n (x, y) jump points of
  * one query as fxjps_plan_batch(_csr) returns them.
  *
@@ -268,6 +269,30 @@ int fxjps_waypoint_st(const int32_t* cells, int32_t n, const int32_t* map_start,
 int fxjps_waypoint_ccst(const int32_t* cells, int32_t n, const uint8_t* occ, int32_t W, int32_t H, double reso, const double* origin,
                         const double* pos, const double* goal, int32_t end_occu, double* out_wp, double* out_goal,
                         int32_t* kept_cells, int32_t* n_kept);
+
+/* ---- The same for every path of a batch.  offsets / cells_xy: the paths as fxjps_plan_batch_csr returns them (nq + 1
+ * offsets, (x, y) pairs); both NULL: the paths of the handle's most recent batch, which are still resident on the
+ * device(s) -- nq must be that batch's.  A query without a path gets the goal as its waypoint (`wp = global_goal`,
+ * scripts/global_planner_st.py:287-290, scripts/global_planner_ccst.py:481-485).  pos, goal, out_wp, out_goal are nq x 3
+ * doubles, end_occu nq flags (NULL: all 0), reso and origin one value for the batch (one grid).
+ *
+ * fxjps_waypoint_ccst_batch runs on the device: one wavefront per path against the RESIDENT grid (the matrix the search
+ * ran on; nothing is passed again) -- near-point deletion, the line-of-sight pruning with map_line_col's float64
+ * raster (np.arange / np.rint / astype(int) are IEEE division, multiplication and round-half-even on the device), the
+ * 1.4 / 0.6 blend; results bit-identical to fxjps_waypoint_ccst path by path.  out_n_kept[q] receives the number of
+ * remaining points, out_kept_cells (optional, kept_capacity pairs >= offsets[nq]) the remaining cells of path q at
+ * offsets[q] (the offsets of the paths themselves).
+ *
+ * fxjps_waypoint_st_batch stays on the host (its decisions hang on libm's atan2, as CPython's do) but takes the whole
+ * batch: nthreads host threads (0: all cores) walk the paths; map_start is nq x 2, prev_wp nq x 3 with prev_dim[q] in
+ * {0: None, 2, 3} (both NULL: no previous waypoints), out_dim / out_ang_wp nq values. */
+int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, const int32_t* cells_xy, double reso, const double* origin,
+                              const double* pos, const double* goal, const int32_t* end_occu, double* out_wp, double* out_goal,
+                              int32_t* out_n_kept, int32_t* out_kept_cells, int64_t kept_capacity);
+int fxjps_waypoint_st_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, const int32_t* cells_xy, const int32_t* map_start, double reso,
+                            const double* origin, const double* pos, const double* goal, const int32_t* end_occu, double dis_wp_tre,
+                            double ang_wp_tre, const double* prev_wp, const int32_t* prev_dim, double* out_wp, int32_t* out_dim,
+                            double* out_goal, double* out_ang_wp, int32_t nthreads);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,21 @@ def test_ccst_pruning_matches_reference_lines():
     assert n == 150 and pruned > 100 and held > 10  # end_occu = 1: the vehicle holds position (ccst:541-544)
 
 
+def test_numpy_oracle_matches_reference_lines():
+    """oracle/waypoints.py (the checker of the device kernel behind fxjps_waypoint_ccst_batch) against the same vectors."""
+    from oracle import waypoints as ow
+    n = 0
+    for rec in cases():
+        if rec["variant"] != 1:
+            continue
+        wp, kept, goal = ow.select_ccst(rec["path"], grid_of(rec).astype(np.float64), rec["reso"], rec["origin"], rec["pos"], rec["goal"],
+                                        rec["end_occu"])
+        exp = rec["out"]
+        assert kept.tolist() == exp["kept"] and wp.tolist() == exp["wp"] and goal.tolist() == exp["goal_out"], n
+        n += 1
+    assert n == 150
+
+
 def test_edge_cases():
     occ = np.zeros((10, 10), dtype=np.uint8)
     # a single-cell path (start == goal): nothing to prune, the waypoint is the goal
