@@ -1684,7 +1684,7 @@ int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_far = take(far_n * sizeof(FarEnt)), o_ci = take(ci_n * 2), o_kf = take(nk * 8), o_of = take(nk * 8), o_kx = take(nk * 4),
-                 o_ox = take(nk * 4), o_os = take(nk * 4), o_sp = take(ns * 4), o_so = take((ns + 1) * 4), o_ok = take(ns * 4), o_in = take(16), o_cn = take(64 * 8);
+                 o_ox = take(nk * 4), o_os = take(nk * 4), o_sp = take(ns * 4), o_so = take((ns + 1) * 4), o_ok = take(ns * 4), o_in = take(32), o_cn = take(64 * 8);
     char* buf = nullptr;
     HIPCHK(h, hipMalloc((void**)&buf, off));
     hipError_t e = hipMemsetAsync(buf, 0, off, d.stream);
@@ -1718,10 +1718,12 @@ int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t
     if (e == hipSuccess && nkeys > 0) e = hipMemcpyAsync(out_slot, buf + o_os, (size_t)nkeys * 4, hipMemcpyDeviceToHost, d.stream);
     if (e == hipSuccess && nsteps > 0) e = hipMemcpyAsync(out_k, buf + o_ok, (size_t)nsteps * 4, hipMemcpyDeviceToHost, d.stream);
     unsigned long long cn[4] = {0, 0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(out_info, buf + o_in, 8, hipMemcpyDeviceToHost, d.stream);
+    uint32_t inf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(inf, buf + o_in, sizeof(inf), hipMemcpyDeviceToHost, d.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(cn, buf + o_cn, sizeof(cn), hipMemcpyDeviceToHost, d.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d.stream);
     (void)hipFree(buf);
+    for (int i = 0; i < 8; i++) out_info[i] = inf[i];
     out_info[2] = (uint32_t)std::min<unsigned long long>(cn[2], 0xFFFFFFFFull);
     out_info[3] = (uint32_t)std::min<unsigned long long>(cn[3], 0xFFFFFFFFull);
     if (e != hipSuccess) return fail(h, FXJPS_E_HIP, "selftest: %s", hipGetErrorString(e));

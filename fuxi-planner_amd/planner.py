@@ -307,13 +307,13 @@ class Planner(object):
         so = np.ascontiguousarray(step_off, dtype=np.uint32)
         n, ns = len(kf), len(sp)
         of, ox, os_ = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
-        ok, info = np.zeros(max(ns, 1), np.uint32), np.zeros(4, np.uint32)
+        ok, info = np.zeros(max(ns, 1), np.uint32), np.zeros(8, np.uint32)
         self._chk(self._L.fxjps_selftest_openlist(self._h, int(bool(banded)), int(far_cap), int(near_max), float(delta0),
                                                   _lib.ptr(kf, C.c_uint64), _lib.ptr(kx, C.c_uint32), n, _lib.ptr(sp, C.c_uint32),
                                                   _lib.ptr(so, C.c_uint32), ns, _lib.ptr(of, C.c_uint64), _lib.ptr(ox, C.c_uint32),
                                                   _lib.ptr(os_, C.c_uint32), _lib.ptr(ok, C.c_uint32), _lib.ptr(info, C.c_uint32)))
         t = int(info[0])
-        return of[:t], ox[:t], os_[:t], ok[:ns], {"fail": int(info[1]), "far_refills": int(info[2]), "slow_pops": int(info[3])}
+        return of[:t], ox[:t], os_[:t], ok[:ns], {"fail": int(info[1]), "far_refills": int(info[2]), "slow_pops": int(info[3]), "held": [int(v) for v in info[4:8]]}
 
     def debug_nbmask(self):
         W, H = self.shape

@@ -237,7 +237,8 @@ int fxjps_selftest_wavemin(fxjps_t* h, int32_t rounds, uint64_t seed, int64_t* m
  * popped keys and the index of the pushed entry each one was, in pop order; out_k[i] the number of pops of step i;
  * out_info[0] the total popped, out_info[1] a failure code (0: none, 1 / 2: a far-tier region was full, 3: more pops
  * than pushes), out_info[2] the refills from the global-memory tier, out_info[3] the pops taken straight from it (more
- * than 256 entries with one and the same full key); out_info holds 4 values.  far_cap / near_max size the global-memory tier as the planner's scratch configuration would (tests
+ * than 256 entries with one and the same full key), out_info[4 .. 7] what the register / LDS / near / far tiers held when
+ * the script ended; out_info holds 8 values.  far_cap / near_max size the global-memory tier as the planner's scratch configuration would (tests
  * make them tiny); delta0 is the first refill width.  The host checks the pops against a binary heap. */
 int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t near_max, double delta0, const uint64_t* keys_f,
                             const uint32_t* keys_x, int64_t nkeys, const uint32_t* step_pops, const uint32_t* step_off, int32_t nsteps,

@@ -88,7 +88,7 @@ def _openlist_script(planner, keys_f, keys_x, step_pops, step_off, expect_fail=F
     if expect_fail:
         assert info["fail"] in (1, 2), info
         return info
-    assert info["fail"] == 0, info
+    assert info["fail"] == 0, (info, len(heap), pos, len(kf))
     while pos < len(of):
         pop_check()
         pos += 1
@@ -96,20 +96,36 @@ def _openlist_script(planner, keys_f, keys_x, step_pops, step_off, expect_fail=F
     return info
 
 
-def _script(rng, n, key_fn, max_pop=16, max_push=24, bursts=True):
+def _script(rng, n, key_fn, max_pop=16, max_push=24, bursts=True, grow=150):
+    """Phases: `grow` steps that push more than they pop (the list reaches a few thousand entries), then steps that
+    mostly pop until about as much has been asked for as was pushed (a step pops at most what the register tier holds,
+    so the list never quite empties before the end)."""
     pops, off, kf, kx = [], [0], [], []
     t = 0
     while len(kf) < n:
-        m = int(rng.integers(0, max_push + 1))
-        if bursts and rng.random() < 0.02:
-            m = 64
-        m = min(m, n - len(kf))
-        f, x = key_fn(t, m)
-        kf.extend(f)
-        kx.extend(x)
-        off.append(len(kf))
-        pops.append(int(rng.integers(0, max_pop + 1)))
-        t += 1
+        grown = 0
+        for _ in range(grow):
+            m = int(rng.integers(0, max_push + 1))
+            if bursts and rng.random() < 0.02:
+                m = 64
+            m = min(m, n - len(kf))
+            f, x = key_fn(t, m)
+            kf.extend(f)
+            kx.extend(x)
+            off.append(len(kf))
+            k = int(rng.integers(0, max_pop + 1))
+            pops.append(k)
+            grown += m - k
+            t += 1
+        while grown > 0 and len(kf) < n:
+            m = min(int(rng.integers(0, 4)), n - len(kf))
+            f, x = key_fn(t, m)
+            kf.extend(f)
+            kx.extend(x)
+            off.append(len(kf))
+            pops.append(64)
+            grown -= 24  # (what such a step really pops, give or take)
+            t += 1
     return np.array(kf, np.float64), np.array(kx, np.uint32), np.array(pops, np.uint32), np.array(off, np.uint32)
 
 
@@ -126,18 +142,18 @@ def test_open_list_alone(planner):
     # 1. an A* frontier: keys a little above a slowly rising floor, more pushes than pops, then the drain
     def astar(t, m):
         return 100.0 + 0.01 * t + rng.random(m) * rng.choice([0.5, 5.0, 50.0]), xy(m)
-    for cfg in ({}, {"far_cap": 2048, "near_max": 48}, {"far_cap": 1024, "near_max": 8, "delta0": 0.05}):
+    for cfg in ({"far_cap": 131072}, {"far_cap": 65536, "near_max": 48}, {"far_cap": 65536, "near_max": 8, "delta0": 0.05}):
         info = _openlist_script(planner, *_script(rng, 60000, astar), **cfg)
         assert info["far_refills"] > 50, info
     # 2. octile-like integer keys: few levels, hundreds of entries each (refills slice one level on (x, y))
     def octile(t, m):
         return (1000 + 10 * (t // 200) + 4 * rng.integers(0, 6, m)).astype(np.float64), xy(m)
-    for cfg in ({"delta0": 20.0}, {"delta0": 20.0, "far_cap": 4096, "near_max": 32}):
+    for cfg in ({"delta0": 20.0, "far_cap": 131072}, {"delta0": 20.0, "far_cap": 65536, "near_max": 32}):
         _openlist_script(planner, *_script(rng, 50000, octile), **cfg)
     # 3. no order at all, and keys far below everything popped so far
     def wild(t, m):
         return np.abs(rng.normal(0.0, 1.0, m)) * 10.0 ** rng.integers(-3, 6), xy(m)
-    _openlist_script(planner, *_script(rng, 40000, wild, max_pop=40), far_cap=8192, near_max=64)
+    _openlist_script(planner, *_script(rng, 40000, wild), far_cap=131072, near_max=64)
     # 4. one and the same full key, thousands of times, among others: the tiers cannot split them
     def flood(t, m):
         f = 50.0 + rng.random(m)
@@ -146,21 +162,21 @@ def test_open_list_alone(planner):
         f[same] = 50.5
         x[same] = (77 << 17) | (99 << 4) | 3
         return f, x
-    info = _openlist_script(planner, *_script(rng, 20000, flood, max_pop=6), far_cap=32768, near_max=128)
+    info = _openlist_script(planner, *_script(rng, 20000, flood, max_pop=6), far_cap=65536, near_max=128)
     assert info["slow_pops"] > 1000, info
-    info = _openlist_script(planner, *_script(rng, 6000, lambda t, m: (np.full(m, 7.0), np.full(m, 5 << 4, np.uint32)), max_pop=3))
+    info = _openlist_script(planner, *_script(rng, 6000, lambda t, m: (np.full(m, 7.0), np.full(m, 5 << 4, np.uint32)), max_pop=3), far_cap=32768)
     assert info["slow_pops"] > 1000, info
     # 5. the far band as a ring of f bands (large grids): set-up, whole bands into M, oversized bands, the last region
     #    dealt out again; cells below 64 x 64 (the ring reads cell infos from the map)
     def wide(t, m):
         return 10.0 + 0.05 * t + rng.random(m) * rng.choice([1.0, 20.0, 300.0]), xy(m, 64)
-    for cfg in ({"far_cap": 65536, "near_max": 128}, {"far_cap": 32768, "near_max": 32, "delta0": 0.5}):
-        info = _openlist_script(planner, *_script(rng, 80000, wide, max_pop=12), banded=True, **cfg)
+    for cfg in ({"far_cap": 262144, "near_max": 128}, {"far_cap": 131072, "near_max": 32, "delta0": 0.5}):
+        info = _openlist_script(planner, *_script(rng, 80000, wide, grow=400), banded=True, **cfg)
         assert info["far_refills"] > 100, info
     # ... and regions that overflow: the failure is reported (the search re-runs such a query on the large pool),
     # what was popped until then is right
-    _openlist_script(planner, *_script(rng, 60000, wide, max_pop=4), banded=True, far_cap=4096, near_max=16, expect_fail=True)
-    _openlist_script(planner, *_script(rng, 30000, astar, max_pop=2), far_cap=256, near_max=16, expect_fail=True)
+    _openlist_script(planner, *_script(rng, 60000, wide, max_pop=4, grow=2000), banded=True, far_cap=4096, near_max=16, expect_fail=True)
+    _openlist_script(planner, *_script(rng, 30000, astar, max_pop=2, grow=2000), far_cap=256, near_max=16, expect_fail=True)
 
 
 # ------------------------------------------------------------------ golden vectors from jps1.py

@@ -53,3 +53,22 @@ for (i, a), (j, b) in zip(marks, marks[1:] + [(len(lines), -1)]):
         hot["writelane"] += wl
     print("%-22s %6d %6d %6d %8d %8d %6d %6d %6d%s" % ("%d -> %d @%d" % (a, b, i), *row, tag))
 print("hot regions: %d instructions, %d spill reloads (v_readlane), %d spill stores (v_writelane)" % (hot["insts"], hot["readlane"], hot["writelane"]))
+# Waits for ALL outstanding vector-memory operations on the first pass through the loop body (loop head .. open_insert):
+# each is a point where the iteration stands still until the previous batch's table stores have landed.  Expected: one
+# behind the lane deal (mark 0: the explicit wait of search_one), the waits of the ray loops (mark 3), one in front of the
+# probe evaluation (mark 5) -- none at the loop head (9), behind open_fill (8) or inside r_refill (FXRT 39 - 41).  (FXRT 42
+# is followed by the whole rarely taken rest of open_fill in the layout: its count means nothing.)
+first = {}
+i9 = next(i for i, l in enumerate(lines) if "FXMARK 9" in l)
+i12 = next(i for i, l in enumerate(lines) if "FXMARK 12" in l)
+cur = None
+for l in lines[i9:i12]:
+    m = re.search(r"(FXMARK|FXRT) (\d+)", l)
+    if m:
+        cur = m.group(1) + " " + m.group(2)
+    elif "s_waitcnt vmcnt(0)" in l:
+        first[cur] = first.get(cur, 0) + 1
+print("s_waitcnt vmcnt(0) between the loop head and open_insert, by the mark in front of them: %s" % first)
+bad = [k for k in first if k in ("FXMARK 9", "FXMARK 8", "FXRT 39", "FXRT 40", "FXRT 41")]
+print("drain-everything waits on the hot path: %s" % (bad if bad else "none"))
+
