@@ -15,7 +15,7 @@ BACKEND_HIP = 1
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
-           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask",
+           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask", "fxjps_debug_read_maps",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst", "fxjps_waypoint_ccst_batch", "fxjps_waypoint_st_batch")
 
 
@@ -116,6 +116,8 @@ def load():
     L.fxjps_selftest_sqrt.argtypes = [vp, C.c_uint32, C.c_uint32, p_f64]
     L.fxjps_selftest_wavemin.restype = C.c_int
     L.fxjps_selftest_wavemin.argtypes = [vp, C.c_int32, C.c_uint64, p_i64]
+    L.fxjps_debug_read_maps.restype = C.c_int
+    L.fxjps_debug_read_maps.argtypes = [vp, C.c_int32, vp, C.c_int64, p_i64]
     p_u32, p_u64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.fxjps_selftest_openlist.restype = C.c_int
     L.fxjps_selftest_openlist.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, p_u64, p_u32, C.c_int64, p_u32, p_u32, C.c_int32,

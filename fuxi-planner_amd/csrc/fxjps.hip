@@ -135,7 +135,14 @@ struct DevCtx {
     DBuf<int32_t> d_wp_eo, d_wp_nkept, d_wp_kept, d_wp_cells, d_wp_len;
     DBuf<long long> d_wp_off;
     DBuf<int32_t> d_upd_xy;
-    DBuf<uint8_t> d_upd_val;
+    DBuf<uint8_t> d_upd_val, d_upd_chg;
+    // what the cell updates since the last rebuild of the derived maps can have changed: the box, in padded
+    // coordinates, of the updated cells and their neighbours; whether the component labels need the full relabelling (a
+    // large update, or 64 small ones, which are united into the existing labels as they come: k_ccl_update)
+    bool dirty = false;
+    int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+    bool ccl_full = false;
+    int ccl_small = 0;
     // pinned staging of a cell-update list: the caller's arrays are copied here before the asynchronous H2D copy, so
     // that they need not outlive the call (ev_upd: the last copy out of the staging buffers has completed)
     HBuf<int32_t> h_upd_xy;
@@ -259,27 +266,48 @@ GridDev grid_of(const DevCtx& d) {
     return G;
 }
 
-// (re)build nb8 + the six scan bitmaps from d.occ
-int derive_maps(fxjps* h, DevCtx& d) {
+// (re)build nb8, the scan bitmaps, the cell infos and the component labels from d.occ.  whole == false: only what the
+// cell updates since the last rebuild can have changed (DevCtx::dirty and its box) -- the neighbour bytes and scan
+// words of the box, the cell infos of the rows and columns through it; the labels were kept up to date by
+// k_ccl_update unless a full relabelling is due.
+int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
     HIPCHK(h, hipSetDevice(d.dev));
-    const long long nrw = (long long)d.PW * d.WORDS, ncw = (long long)d.PH * d.WORDS;
-    hipLaunchKernelGGL(fx::k_derive_rows, dim3((unsigned)((nrw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, grid_of(d),
-                       d.nb8.p, d.bm.p);
-    hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, grid_of(d),
-                       d.bm.p);
-    {
-        const long long ncell = (long long)d.PW * d.PH;
-        hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream,
-                           grid_of(d), d.ci.p);
+    if (!whole && !d.dirty && !d.ccl_full) return FXJPS_OK;
+    const bool box = !whole && d.dirty && (d.bx1 - d.bx0 + 1) * 2 <= d.PW && (d.by1 - d.by0 + 1) * 2 <= d.PH;
+    const GridDev G = grid_of(d);
+    if (whole || d.dirty) {
+        fx::MapRange rr{0, d.PW - 1, 0, d.WORDS - 1}, rc{0, d.PH - 1, 0, d.WORDS - 1};
+        if (box) {
+            rr = fx::MapRange{d.bx0, d.bx1, d.by0 >> 6, d.by1 >> 6};
+            rc = fx::MapRange{d.by0, d.by1, d.bx0 >> 6, d.bx1 >> 6};
+        }
+        const long long nrw = (long long)(rr.l1 - rr.l0 + 1) * (rr.w1 - rr.w0 + 1), ncw = (long long)(rc.l1 - rc.l0 + 1) * (rc.w1 - rc.w0 + 1);
+        hipLaunchKernelGGL(fx::k_derive_rows, dim3((unsigned)((nrw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G, d.nb8.p, d.bm.p, rr);
+        hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G, d.bm.p, rc);
+        if (box) {  // the rows and the columns through the box (a straight jump ends where the line's next stop bit is)
+            const fx::MapRange sa{d.bx0, d.bx1, 0, d.PH - 1}, sb{0, d.PW - 1, d.by0, d.by1};
+            const long long na = (long long)(sa.l1 - sa.l0 + 1) * d.PH, nb = (long long)d.PW * (sb.w1 - sb.w0 + 1);
+            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa);
+            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sb);
+        } else {
+            const long long ncell = (long long)d.PW * d.PH;
+            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p,
+                               fx::MapRange{0, d.PW - 1, 0, d.PH - 1});
+        }
+        HIPCHK(h, hipGetLastError());
     }
-    HIPCHK(h, hipGetLastError());
-    // component labels for the unreachable-goal early-out
-    const long long n = (long long)d.W * d.H;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(fx::k_ccl_init, dim3(nb), dim3(256), 0, d.stream, d.occ.p, n, d.comp.p);
-    hipLaunchKernelGGL(fx::k_ccl_merge, dim3(nb), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.comp.p);
-    hipLaunchKernelGGL(fx::k_ccl_flatten, dim3(nb), dim3(256), 0, d.stream, n, d.comp.p);
-    HIPCHK(h, hipGetLastError());
+    if (whole || d.ccl_full) {
+        // component labels for the unreachable-goal early-out
+        const long long n = (long long)d.W * d.H;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(fx::k_ccl_init, dim3(nb), dim3(256), 0, d.stream, d.occ.p, n, d.comp.p);
+        hipLaunchKernelGGL(fx::k_ccl_merge, dim3(nb), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.comp.p);
+        hipLaunchKernelGGL(fx::k_ccl_flatten, dim3(nb), dim3(256), 0, d.stream, n, d.comp.p);
+        HIPCHK(h, hipGetLastError());
+        d.ccl_small = 0;
+    }
+    d.dirty = false;
+    d.ccl_full = false;
     return FXJPS_OK;
 }
 
@@ -859,6 +887,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_wp_off.release();
         d.d_upd_xy.release();
         d.d_upd_val.release();
+        d.d_upd_chg.release();
         d.h_len.release();
         d.h_cells.release();
         d.h_cost.release();
@@ -1117,6 +1146,21 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "cell update before fxjps_set_grid");
     if (n < 0 || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
     if (n == 0 && !(derive && h->maps_stale)) return FXJPS_OK;
+    // the box of the cells of the list that lie on the grid
+    int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+    bool have_box = false;
+    {
+        const DevCtx& d0 = h->devs[0];
+        for (int64_t i = 0; i < n; i++) {
+            const int x = xy[2 * i], y = xy[2 * i + 1];
+            if (x < 0 || y < 0 || x >= d0.W || y >= d0.H) continue;
+            bx0 = have_box ? std::min(bx0, x) : x;
+            bx1 = have_box ? std::max(bx1, x) : x;
+            by0 = have_box ? std::min(by0, y) : y;
+            by1 = have_box ? std::max(by1, y) : y;
+            have_box = true;
+        }
+    }
     // every device applies the same (small) update list; cheaper than re-broadcasting the grid
     for (auto& d : h->devs) {
         HIPCHK(h, hipSetDevice(d.dev));
@@ -1137,14 +1181,37 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
             HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, d.h_upd_val.p, (size_t)n, hipMemcpyHostToDevice, d.stream));
         }
         if (n > 0) {
-            hipLaunchKernelGGL(fx::k_update_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d.stream, d.occ.p,
-                               d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p, (long long)n);
+            HIPCHK(h, d.d_upd_chg.ensure((size_t)n));
+            const unsigned nbk = (unsigned)((n + 255) / 256);
+            hipLaunchKernelGGL(fx::k_update_cells, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p,
+                               (long long)n, d.d_upd_chg.p);
+            // the labels: a small update is united into them right away (the list is on the device now, not when the
+            // maps are rebuilt); a large one, and every 64th small one, asks for the full relabelling
+            static const long long small_max = getenv("FXJPS_CCL_SMALL") ? atoll(getenv("FXJPS_CCL_SMALL")) : 8192;  // (0: always relabel)
+            if (!d.ccl_full && n <= small_max && d.ccl_small < 64) {
+                hipLaunchKernelGGL(fx::k_ccl_update, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_chg.p, (long long)n,
+                                   d.comp.p, 0);
+                hipLaunchKernelGGL(fx::k_ccl_update, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_chg.p, (long long)n,
+                                   d.comp.p, 1);
+                d.ccl_small++;
+            } else {
+                d.ccl_full = true;
+            }
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(d.ev_upd, d.stream));
             d.upd_pending = true;
+            if (have_box) {  // padded coordinates: cell x sits at x + 1, its neighbours at x .. x + 2
+                const int x0 = std::max(bx0, 0), x1 = std::min(bx1 + 2, d.PW - 1), y0 = std::max(by0, 0), y1 = std::min(by1 + 2, d.PH - 1);
+                d.bx0 = d.dirty ? std::min(d.bx0, x0) : x0;
+                d.bx1 = d.dirty ? std::max(d.bx1, x1) : x1;
+                d.by0 = d.dirty ? std::min(d.by0, y0) : y0;
+                d.by1 = d.dirty ? std::max(d.by1, y1) : y1;
+                d.dirty = true;
+            }
         }
         if (derive) {
-            int rc = derive_maps(h, d);
+            static const bool partial = !(getenv("FXJPS_PARTIAL_DERIVE") && atoi(getenv("FXJPS_PARTIAL_DERIVE")) == 0);  // (0: measurement / test aid)
+            int rc = derive_maps(h, d, !partial);
             if (rc) return rc;
         }
     }
@@ -1727,6 +1794,32 @@ int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t
     out_info[2] = (uint32_t)std::min<unsigned long long>(cn[2], 0xFFFFFFFFull);
     out_info[3] = (uint32_t)std::min<unsigned long long>(cn[3], 0xFFFFFFFFull);
     if (e != hipSuccess) return fail(h, FXJPS_E_HIP, "selftest: %s", hipGetErrorString(e));
+    return FXJPS_OK;
+}
+
+int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity_bytes, int64_t* out_bytes) {
+    if (!h) return FXJPS_E_ARG;
+    if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
+    DevCtx& d = h->devs[0];
+    HIPCHK(h, hipSetDevice(d.dev));
+    if (h->maps_stale) {  // deferred cell updates: the maps follow the grid first
+        int rc = update_cells_async(h, nullptr, nullptr, 0, true);
+        if (rc) return rc;
+    }
+    const void* src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = d.bm.p; bytes = (size_t)4 * d.LINES * d.WORDS * sizeof(fx::BmWord); break;  // scan words [4][LINES][WORDS] x {stop, occ}
+        case 1: src = d.ci.p; bytes = (size_t)d.PW * d.NS * sizeof(uint16_t); break;               // cell infos [PW][NS] (columns >= PH unused)
+        case 2: src = d.comp.p; bytes = (size_t)d.W * d.H * sizeof(int); break;                    // component forest [W][H]
+        case 3: src = d.nb8.p; bytes = (size_t)d.PW * d.NS; break;                                 // neighbour bytes [PW][NS]
+        default: return fail(h, FXJPS_E_ARG, "which must be 0 .. 3");
+    }
+    if (out_bytes) *out_bytes = (int64_t)bytes;
+    if (!buf) return FXJPS_OK;
+    if (capacity_bytes < (int64_t)bytes) return fail(h, FXJPS_E_ARG, "buffer holds %lld bytes, the map has %zu", (long long)capacity_bytes, bytes);
+    HIPCHK(h, hipMemcpyAsync(buf, src, bytes, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
     return FXJPS_OK;
 }
 

@@ -315,6 +315,24 @@ class Planner(object):
         t = int(info[0])
         return of[:t], ox[:t], os_[:t], ok[:ns], {"fail": int(info[1]), "far_refills": int(info[2]), "slow_pops": int(info[3]), "held": [int(v) for v in info[4:8]]}
 
+    def debug_maps(self):
+        """The derived device maps (fxjps_debug_read_maps): {"bm": uint64[4, LINES, WORDS, 2], "ci": uint16[W+2, H+2],
+        "comp": int32[W, H] (union-find parent links), "nb8": uint8[W+2, H+2]}."""
+        W, H = self.shape
+        PW, PH = W + 2, H + 2
+        NS = (PH + 63) & ~63
+        LINES = max(PW, PH)
+        WORDS = (LINES + 63) // 64
+        out = {}
+        for which, name, dt, shape in ((0, "bm", np.uint64, (4, LINES, WORDS, 2)), (1, "ci", np.uint16, (PW, NS)), (2, "comp", np.int32, (W, H)),
+                                       (3, "nb8", np.uint8, (PW, NS))):
+            a = np.zeros(shape, dtype=dt)
+            nb = C.c_int64(0)
+            self._chk(self._L.fxjps_debug_read_maps(self._h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.byref(nb)))
+            assert nb.value == a.nbytes, (name, nb.value, a.nbytes)
+            out[name] = a[:, :PH] if name in ("ci", "nb8") else a
+        return out
+
     def debug_nbmask(self):
         W, H = self.shape
         buf = np.empty((W + 2, H + 2), dtype=np.uint8)

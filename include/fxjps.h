@@ -248,6 +248,13 @@ int fxjps_selftest_openlist(fxjps_t* h, int32_t banded, int32_t far_cap, int32_t
  * (W+2)x(H+2) neighbour-mask bytes.  buf must hold (W+2)*(H+2) bytes. */
 int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
 
+/* The derived device maps as they are (tests compare them after cell updates -- which rebuild only what the changed
+ * cells can reach -- with those of a fresh upload): which = 0 the scan words ([4][LINES][WORDS] pairs of u64 {stop, occ},
+ * LINES = max(W, H) + 2, WORDS = ceil(LINES / 64)), 1 the cell infos (u16 [W + 2][NS], NS = H + 2 rounded up to 64; the
+ * columns from H + 2 on are unused), 2 the component forest (int32 [W][H]: parent links, a root points at itself, -1
+ * never free), 3 the neighbour bytes ([W + 2][NS]).  out_bytes receives the size; buf == NULL: the size only. */
+int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity_bytes, int64_t* out_bytes);
+
 /* ---- Waypoint selection after a plan.  One path per call, host functions (no device work, no handle;
  * the batch forms below take the grid from the handle and run the ccst pruning on the device):
  * the step the reference's nodes run on the path jps1.method returned.  `cells` are the n (x, y) jump points of

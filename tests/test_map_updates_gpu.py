@@ -1,0 +1,124 @@
+"""GPU suite (-m gpu): cell updates rebuild only what the changed cells can reach -- the neighbour bytes and
+scan words of their box, the cell infos of the rows and columns through it -- and unite small updates into the component
+labels instead of relabelling the map.  After every update the derived device maps are compared byte for byte with those
+of a fresh upload of the same grid on a second handle; the component forest must keep together whatever the fresh labels
+keep together (it may be coarser where an update split a component: those queries are searched, not answered at once);
+plans on the updated handle equal the oracle's."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def roots(par):
+    r = par.astype(np.int64).ravel().copy()
+    idx = np.flatnonzero(r >= 0)
+    while True:
+        nxt = r[r[idx]]
+        if np.array_equal(nxt, r[idx]):
+            return r
+        r[idx] = nxt
+
+
+def check_against_fresh(p, q, cur, tag):
+    q.set_grid_occ(cur)
+    a, b = p.debug_maps(), q.debug_maps()
+    for k in ("nb8", "bm", "ci"):
+        assert np.array_equal(a[k], b[k]), (tag, k, int((a[k] != b[k]).sum()))
+    free = np.flatnonzero(cur.ravel() == 0)
+    ra, rb = roots(a["comp"])[free], roots(b["comp"])[free]
+    assert (ra >= 0).all() and (rb >= 0).all(), tag
+    pairs = np.unique(np.stack([rb, ra]), axis=1)
+    assert pairs.shape[1] == len(np.unique(rb)), (tag, "a fresh component is split over several roots")
+    return len(np.unique(ra)), len(np.unique(rb))
+
+
+def test_partial_rebuild_equals_fresh_upload(oracle):
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import synth
+    from test_gpu_parity import gpu_vs_oracle
+    rng = np.random.default_rng(77)
+    with fx.Planner([0]) as p, fx.Planner([0]) as q:
+        for (W, H, dens) in ((1024, 1024, 0.20), (700, 333, 0.3), (130, 2100, 0.15), (65, 64, 0.4)):
+            cur = (rng.random((W, H)) < dens).astype(np.uint8)
+            p.set_grid_occ(cur)
+            s, g = synth.synth_queries(cur, 3, 300)
+            coarse = 0
+            for step in range(90):
+                kind = step % 9
+                rebuild = True
+                if kind in (0, 1):      # a sensor window, all its cells sent, fresh values
+                    w = int(rng.integers(1, min(64, W, H) + 1))
+                    x0, y0 = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - w + 1))
+                    xs, ys = np.meshgrid(np.arange(x0, x0 + w), np.arange(y0, y0 + w), indexing="ij")
+                    xy = np.stack([xs.ravel(), ys.ravel()], 1)
+                    val = (rng.random(len(xy)) < dens).astype(np.uint8)
+                elif kind == 2:         # corners and borders
+                    xy = np.array([[0, 0], [W - 1, H - 1], [0, H - 1], [W - 1, 0], [W // 2, 0], [0, H // 2]])
+                    val = rng.integers(0, 2, len(xy)).astype(np.uint8)
+                elif kind == 3:         # a wall across the map, then (next time) gone again: components split and merge
+                    x = int(rng.integers(1, W - 1))
+                    xy = np.stack([np.full(H, x), np.arange(H)], 1)
+                    val = np.full(H, (step // 9) % 2 == 0, dtype=np.uint8)
+                elif kind == 4:         # nothing changes
+                    xy = np.stack([rng.integers(0, W, 40), rng.integers(0, H, 40)], 1)
+                    val = cur[xy[:, 0], xy[:, 1]].copy()
+                elif kind == 5:         # two deferred updates, the next one rebuilds
+                    xy = np.unique(np.stack([rng.integers(0, W, 30), rng.integers(0, H, 30)], 1), axis=0)
+                    val = rng.integers(0, 2, len(xy)).astype(np.uint8)
+                    rebuild = False
+                elif kind == 6:
+                    xy = np.unique(np.stack([rng.integers(0, W, 30), rng.integers(0, H, 30)], 1), axis=0)
+                    val = rng.integers(0, 2, len(xy)).astype(np.uint8)
+                    rebuild = False
+                elif kind == 7:         # a single cell
+                    xy = np.array([[int(rng.integers(0, W)), int(rng.integers(0, H))]])
+                    val = 1 - cur[xy[:, 0], xy[:, 1]]
+                else:                   # large: more cells than the labels take incrementally (full relabelling)
+                    k = min(W * H // 3, 20000)
+                    idx = rng.choice(W * H, k, replace=False)
+                    xy = np.stack([idx // H, idx % H], 1)
+                    val = rng.integers(0, 2, k).astype(np.uint8)
+                cur[xy[:, 0], xy[:, 1]] = val
+                p.update_cells(xy.astype(np.int32), val.astype(np.uint8), rebuild=rebuild)
+                if rebuild:
+                    na, nb = check_against_fresh(p, q, cur, (W, H, step, kind))
+                    coarse += na < nb
+            gpu_vs_oracle(p, oracle, cur, s, g, 2)  # and the searches on the updated handle are the oracle's
+            gpu_vs_oracle(p, oracle, cur, s, g, 1)
+            print("partial rebuilds on %dx%d: %d of 70 states with coarser labels than a fresh relabelling" % (W, H, coarse))
+        # 70 small updates in a row: the 65th asks for the full relabelling
+        cur = (rng.random((512, 512)) < 0.35).astype(np.uint8)
+        p.set_grid_occ(cur)
+        for step in range(70):
+            xy = np.array([[int(rng.integers(0, 512)), int(rng.integers(0, 512))]])
+            val = 1 - cur[xy[:, 0], xy[:, 1]]
+            cur[xy[:, 0], xy[:, 1]] = val
+            p.update_cells(xy.astype(np.int32), val.astype(np.uint8))
+        na, nb = check_against_fresh(p, q, cur, "70 small")
+        assert na <= nb
+
+
+def test_window_update_on_a_large_map_is_cheap():
+    """A 64 x 64 window re-observed on 4096 x 4096: the rebuild touches 66 lines and the rows / columns through them,
+    not 16 M cells and their labels (before: about 2 ms)."""
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(4096, 4096, 2, 0.20)
+    rng = np.random.default_rng(5)
+    with fx.Planner([0]) as p:
+        p.set_grid_occ(occ)
+        ts = []
+        for rep in range(40):
+            x0, y0 = int(rng.integers(0, 4096 - 64)), int(rng.integers(0, 4096 - 64))
+            xs, ys = np.meshgrid(np.arange(x0, x0 + 64), np.arange(y0, y0 + 64), indexing="ij")
+            xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+            val = (rng.random(len(xy)) < 0.2).astype(np.uint8)
+            t = time.perf_counter()
+            p.update_cells(xy, val)
+            ts.append(time.perf_counter() - t)
+        ts = np.array(ts[8:]) * 1e3
+        print("64x64 window update at 4096^2: median %.3f ms, max %.3f ms (host call, blocking)" % (np.median(ts), ts.max()))
+        assert np.median(ts) < 0.6
