@@ -12,10 +12,16 @@ STEPS=${@:-tests bench}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# a GPU fault ends the session: nothing else is started on a device that has just faulted
+chk() { if grep -q "Memory access fault\|HSA_STATUS_ERROR\|GPU coredump" "$@" 2>/dev/null; then echo "GPU FAULT reported in $*: stopping"; exit 3; fi; }
 for s in $STEPS; do
 case $s in
 tests)
-  timeout 2400 python -m pytest tests -m gpu -q -s -x --durations=15 > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log;;
+  timeout 2400 python -m pytest tests -m gpu -q -s -x --durations=15 > $OUT/pytest.log 2>&1; rc=$?; echo "rc=$rc" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
+  chk $OUT/pytest.log; if [ $rc -ne 0 ]; then exit 4; fi;;
+quick)
+  timeout 1200 python -m pytest tests -m gpu -q -x --durations=8 -k "${FX_TESTS:-open_list or map_updates or partial or window or deferred or streaming or config5 or update_cells}" > $OUT/pytest_quick.log 2>&1; rc=$?; echo "rc=$rc" >> $OUT/pytest_quick.log; tail -12 $OUT/pytest_quick.log
+  chk $OUT/pytest_quick.log; if [ $rc -ne 0 ]; then exit 4; fi;;
 bench)
   timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default rc=$?"; cut -c1-3000 $OUT/bench_default.json
   timeout 600 python bench.py --workload c4 --inlib --gpus 1 --steps 2 --warmup 1 > $OUT/bench_c4_n1.json 2> $OUT/bench_c4_n1.err; echo "c4 rc=$?"; cut -c1-1200 $OUT/bench_c4_n1.json
@@ -38,6 +44,12 @@ profiles)
     timeout 900 python bench.py --workload $w --steps 5 --warmup 2 --no-also > $P/bench.json 2> $P/bench.err
     python3 tools/profile_summary.py $P $w > $P/summary.json 2> $P/summary.err; cut -c1-400 $P/summary.json
   done;;
+multi)
+  # the two N > 1 code paths of bench.py on a one-GPU box: every rank / context on device 0 (everything but the collective)
+  FXJPS_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_inlib2.json 2> $OUT/bench_inlib2.err; echo "inlib x2 rc=$?"; cut -c1-1500 $OUT/bench_inlib2.json
+  chk $OUT/bench_inlib2.err
+  FXJPS_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 > $OUT/bench_torchrun2.json 2> $OUT/bench_torchrun2.err; echo "torchrun x2 (gloo, one device) rc=$?"; grep "^{" $OUT/bench_torchrun2.json | cut -c1-1500
+  chk $OUT/bench_torchrun2.err;;
 busy)
   for w in c2 c4shard; do
     P=$OUT/busy_$w; rm -rf $P
