@@ -12,7 +12,8 @@ generator fuxi-planner_amd/synth.py):
     c4       BASELINE config 4 itself: 1 000 000 queries split over the N GPUs (strong scaling; N = 1: all of them)
     c5       BASELINE config 5, streaming replan: a step is one frame = toggle 10 % of the cells + rebuild the maps +
              plan the 1 000 persistent queries (SURVEY 8d toggle stream); c5low = the same with 0.1 % toggles;
-             c5local = one 64 x 64 window re-observed per frame (the exact-reuse case of fxjps_replan_frame);
+             c5local = one 64 x 64 window re-observed per frame (the exact-reuse case of fxjps_replan_frame), c5local4k =
+             the same on the 4096 x 4096 grid of config 3;
              c5pipe = config 5 with frames in flight (fuxi_planner_amd.replan.FramePipeline: K planner handles on the
              GPU take the frames in turn): sustained frames/s and p50 / p99 submit-to-paths latency over the 600 frames
              SURVEY 8d prescribes (its default --steps)
@@ -218,7 +219,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5pipe"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5local4k", "c5pipe"])
     ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N) (the default when "
                     "bench.py is not started by torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

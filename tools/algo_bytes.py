@@ -40,6 +40,10 @@ WORKLOADS = {
     "c5local": dict(C2, qseed=5, nq=1000, max_path_len=2048, toggle_frac=0.0, toggle_mode="local", window=64, toggle_seed=5, frames=40,
                     describe="config 5 with local churn (the ROS node's ticks: the map changes where the vehicle looks): per frame one 64x64 "
                              "window, moving with the frame index, is re-observed (all its cells sent, fresh 20% values), 1000 persistent queries"),
+    "c5local4k": dict(W=4096, H=4096, grid_seed=2, p=0.20, qseed=5, hchoice=2, nq=1000, max_path_len=8192, toggle_frac=0.0, toggle_mode="local",
+                      window=64, toggle_seed=5, frames=8, cpu_sample=256, cpu_threads=64,
+                      describe="streaming replan at the size of config 3: 4096x4096 grid (seed 2), per frame one 64x64 window re-observed, 1000 persistent "
+                               "queries (qseed 5): the read-set instantiation on hashed tables, partial map rebuilds, united component labels"),
 }
 PIPE_FRAMES = 8  # c5pipe: config 5 with this many frames in flight (same frames, same counts: derived from c5)
 NT = min(os.cpu_count() or 8, 256)
@@ -73,13 +77,13 @@ def main():
             for fr in range(w["frames"]):
                 xy, val = synth.frame_update(occ, keep, fr, w)
                 synth.apply_toggles(occ, xy, val)
-                c, ln = count(occ, s, g, w["hchoice"], w["max_path_len"])
+                c, ln = count(occ, s, g, w["hchoice"], w["max_path_len"], nthreads=min(NT, w.get("cpu_threads", NT)))
                 per.append(c["algorithmic_bytes"])
                 reach.append(int((ln > 0).sum()))
                 if fr % 20 == 19:
                     print("%s frame %d of %d, %.0f s" % (name, fr + 1, w["frames"], time.time() - t), flush=True)
             rec.update(algorithmic_bytes_per_frame=per, reachable_per_frame=reach, algorithmic_bytes=int(np.mean(per)),
-                       algorithmic_bytes_source="oracle literal mode, all 1000 queries of each of the first %d frames" % w["frames"])
+                       algorithmic_bytes_source="oracle literal mode, all %d queries of each of the first %d frames" % (w["nq"], w["frames"]))
         else:
             n = w.get("sample", w["nq"])
             s, g = oracle.synth_queries(occ, w["qseed"], n)

@@ -31,7 +31,7 @@ lines)
     timeout 900 python bench.py --workload $w --steps 5 --warmup 2 --no-also > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w rc=$?"; cut -c1-420 $OUT/bench_$w.json
   done;;
 algo5)
-  timeout 1500 python tools/algo_bytes.py c5 > $OUT/algo_bytes.log 2>&1; cp fuxi-planner_amd/workloads.json $OUT/workloads.json; tail -3 $OUT/algo_bytes.log | cut -c1-300;;
+  timeout 1500 python tools/algo_bytes.py c5 c5local4k > $OUT/algo_bytes.log 2>&1; cp fuxi-planner_amd/workloads.json $OUT/workloads.json; tail -3 $OUT/algo_bytes.log | cut -c1-300;;
 profiles)
   for w in ${FX_PROFILE_WORKLOADS:-c2 c2h1 c4shard c5 c5local c3}; do
     P=$OUT/prof_$w; rm -rf $P; mkdir -p $P
