@@ -122,3 +122,44 @@ def test_window_update_on_a_large_map_is_cheap():
         ts = np.array(ts[8:]) * 1e3
         print("64x64 window update at 4096^2: median %.3f ms, max %.3f ms (host call, blocking)" % (np.median(ts), ts.max()))
         assert np.median(ts) < 0.6
+
+
+def test_odd_update_lists_and_several_contexts(oracle):
+    """Cells outside the grid in the list (ignored), an empty list, a list that repeats the resident values, a deferred
+    update followed by a new grid of another size (the leftover box must not reach into the new maps) -- on a handle with
+    three contexts on the device (each applies the list and rebuilds its own maps): plans equal the oracle's and those
+    of a one-context handle, the maps of the first context equal a fresh upload."""
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import synth
+    from test_gpu_parity import gpu_vs_oracle
+    rng = np.random.default_rng(9)
+    with fx.Planner([0, 0, 0]) as p3, fx.Planner([0]) as q:
+        cur = synth.synth_grid(300, 200, 8, 0.25)
+        s, g = synth.synth_queries(cur, 8, 400)
+        p3.set_grid_occ(cur)
+        xy = np.array([[-1, 5], [300, 5], [5, -1], [5, 200], [10, 10], [299, 199], [0, 0]], dtype=np.int32)
+        val = np.array([1, 1, 1, 1, 1, 1, 1], dtype=np.uint8)
+        ok = (xy[:, 0] >= 0) & (xy[:, 0] < 300) & (xy[:, 1] >= 0) & (xy[:, 1] < 200)
+        cur[xy[ok, 0], xy[ok, 1]] = val[ok]
+        p3.update_cells(xy, val)
+        check_against_fresh(p3, q, cur, "outside cells")
+        p3.update_cells(np.zeros((0, 2), np.int32), np.zeros(0, np.uint8))
+        p3.update_cells(np.array([[-5, -5]], np.int32), np.array([1], np.uint8))       # nothing on the grid at all
+        p3.update_cells(xy[ok], cur[xy[ok, 0], xy[ok, 1]])                               # the resident values again
+        check_against_fresh(p3, q, cur, "no-op lists")
+        gpu_vs_oracle(p3, oracle, cur, s, g, 2)
+        # a deferred update, then a new (smaller) grid: the old box is forgotten
+        p3.update_cells(np.array([[290, 190]], np.int32), np.array([1], np.uint8), rebuild=False)
+        cur = synth.synth_grid(90, 120, 3, 0.2)
+        s, g = synth.synth_queries(cur, 3, 300)
+        p3.set_grid_occ(cur)
+        check_against_fresh(p3, q, cur, "new grid behind a deferred update")
+        for step in range(6):
+            k = int(rng.integers(1, 200))
+            idx = rng.choice(90 * 120, k, replace=False)
+            xy = np.stack([idx // 120, idx % 120], 1).astype(np.int32)
+            val = rng.integers(0, 2, k).astype(np.uint8)
+            cur[xy[:, 0], xy[:, 1]] = val
+            p3.update_cells(xy, val, rebuild=step % 2 == 0)
+        gpu_vs_oracle(p3, oracle, cur, s, g, 2)
+        check_against_fresh(p3, q, cur, "after mixed updates")

@@ -111,3 +111,31 @@ def test_waypoints_follow_a_streaming_frame_and_shards(planner):
         assert all(x.tobytes() == y.tobytes() for x, y in zip(got, ref))
         with pytest.raises(fx.FxjpsError):
             waypoints.select_ccst_batch(p3, len(s) - 1, 1.0, (0.0, 0.0), pos[1:], goal[1:])  # not the last batch's size
+
+
+def test_batch_edges(planner):
+    """Empty batch, paths of one, two and three points, every flag set, a path of several hundred collinear points (the
+    kernel's 64-point windows): the batch kernel equals the one-path function."""
+    from fuxi_planner_amd import waypoints
+    occ = np.zeros((400, 40), dtype=np.uint8)
+    occ[200, 5:35] = 1
+    planner.set_grid_occ(occ)
+    wp, g, nk = waypoints.select_ccst_batch(planner, 0, 1.0, (0.0, 0.0), np.zeros((0, 3)), np.zeros((0, 3)), paths=(np.zeros(1, np.int64), np.zeros((0, 2), np.int32)))
+    assert wp.shape == (0, 3) and nk.shape == (0,)
+    paths = [[(3, 3)], [(3, 3), (9, 9)], [(3, 3), (9, 9), (9, 20)], [(x, 2) for x in range(0, 399)], [(x, 2) for x in range(0, 190)] + [(190, 3), (199, 12), (199, 36), (201, 38), (230, 38)],
+             [(0, 0), (1, 1)], []]
+    off = np.zeros(len(paths) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(p) for p in paths])
+    cells = np.array([c for p in paths for c in p], dtype=np.int32).reshape(-1, 2)
+    n = len(paths)
+    rng = np.random.default_rng(1)
+    pos = np.c_[rng.uniform(0, 10, n), rng.uniform(0, 10, n), rng.uniform(0, 2, n)]
+    goal = np.c_[rng.uniform(0, 400, n), rng.uniform(0, 40, n), np.ones(n)]
+    for eo in (np.zeros(n, np.int32), np.ones(n, np.int32)):
+        wp, gout, nk, kept = waypoints.select_ccst_batch(planner, n, 0.5, (1.0, -2.0), pos, goal, eo, paths=(off, cells), return_kept=True)
+        for q, p in enumerate(paths):
+            if not p:
+                assert nk[q] == 0 and np.array_equal(wp[q], goal[q])
+                continue
+            w1, k1, g1 = waypoints.select_ccst(p, occ, 0.5, (1.0, -2.0), pos[q], goal[q], int(eo[q]), return_goal=True)
+            assert np.array_equal(kept[off[q]:off[q] + nk[q]], k1) and wp[q].tobytes() == w1.tobytes() and gout[q].tobytes() == g1.tobytes(), q
