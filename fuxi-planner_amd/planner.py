@@ -331,6 +331,10 @@ class Planner(object):
             self._chk(self._L.fxjps_debug_read_maps(self._h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.byref(nb)))
             assert nb.value == a.nbytes, (name, nb.value, a.nbytes)
             out[name] = a[:, :PH] if name in ("ci", "nb8") else a
+        # (lines the kernels neither write nor read -- the +-x scans have a line per padded y, the +-y scans per padded
+        # x, the array has max(PW, PH) of each -- hold whatever the allocation held)
+        out["bm"][0:2, PH:] = 0
+        out["bm"][2:4, PW:] = 0
         return out
 
     def debug_nbmask(self):
