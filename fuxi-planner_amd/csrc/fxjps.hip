@@ -694,7 +694,10 @@ typedef int (*nccl_destroy_t)(void*);
 
 int broadcast_grid(fxjps* h, int W, int H) {
     const int nd = (int)h->devs.size();
-    if (nd == 1) return FXJPS_OK;
+    // (FXJPS_FORCE_RCCL=1: test aid -- a one-device handle goes through the collective too: a communicator of one rank,
+    // an in-place broadcast from itself.  Exercises the loading of librccl, the symbols, their signatures and the
+    // communicator's life cycle on a one-GPU box.)
+    if (nd == 1 && !(getenv("FXJPS_FORCE_RCCL") && atoi(getenv("FXJPS_FORCE_RCCL")) != 0)) return FXJPS_OK;
     bool distinct = true;
     for (int a = 0; a < nd; a++)
         for (int b = a + 1; b < nd; b++)

@@ -565,6 +565,50 @@ def test_in_library_sharding_on_one_gpu(planner):
         assert p4.timing()["reused"] > 0
 
 
+_RCCL1 = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ["FXJPS_FORCE_RCCL"] = "1"
+import numpy as np
+import fuxi_planner_amd as fx
+from fuxi_planner_amd import synth
+occ = synth.synth_grid(300, 260, 12, 0.20)
+s, g = synth.synth_queries(occ, 12, 500)
+with fx.Planner([0]) as p:
+    p.set_grid_occ(occ)                              # H2D + ncclBroadcast (root = the only rank, in place)
+    info = p.comm_info()
+    res = p.plan_batch(s, g, 2, 512)
+    occ2 = occ.copy(); occ2[5:9, 5:9] = 1
+    p.set_grid_occ(occ2)                             # the communicator is reused
+    res2 = p.plan_batch(s, g, 2, 512)
+os.environ["FXJPS_FORCE_RCCL"] = "0"
+with fx.Planner([0]) as p:
+    p.set_grid_occ(occ)
+    ref = p.plan_batch(s, g, 2, 512)
+    p.set_grid_occ(occ2)
+    ref2 = p.plan_batch(s, g, 2, 512)
+assert all(np.array_equal(a, b) for a, b in zip(res, ref)) and all(np.array_equal(a, b) for a, b in zip(res2, ref2))
+print("RCCL1-OK", info)
+'''
+
+
+def test_rccl_path_with_one_rank(tmp_path):
+    """The in-library collective on a one-GPU box: FXJPS_FORCE_RCCL=1 sends a one-device handle through dlopen(librccl),
+    ncclCommInitAll, ncclGroupStart / ncclBroadcast / ncclGroupEnd and ncclCommDestroy with a communicator of one rank
+    (ncclCommCount == 1 through fxjps_comm_info); the grid that arrives is the grid that was sent.  Own process with a
+    time limit: a communicator that cannot come up in this environment skips the test, it does not hang the suite."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(_RCCL1 % {"root": ROOT})
+    try:
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL did not initialise within 240 s on this box")
+    if r.returncode != 0 and ("fxjps error -6" in r.stderr or "ncclCommInitAll" in r.stderr or "librccl" in r.stderr):
+        pytest.skip("RCCL is not usable on this box: " + r.stderr[-300:])
+    assert r.returncode == 0 and "RCCL1-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "'rccl_ranks': 1" in r.stdout, r.stdout
+
+
 def test_in_library_multi_device_handle(planner):
     """fxjps_create(n_dev = 2): RCCL broadcast of the grid + contiguous shards inside the library (no torch)."""
     import fuxi_planner_amd as fx
