@@ -12,7 +12,7 @@ c3 counts a 2 000-query literal sample and extrapolates (x 50) -- the oracle nee
 the toggle stream (16 warm-up frames + the 600 frames SURVEY 8d prescribes; c5pipe is the same stream), c5low / c5local
 for the first 40.  Meant for a many-core host (the GPU box: ~5 min on 256 threads, c5 alone ~10 min).
 """
-import json, os, sys, time
+import json, os, re, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -108,8 +108,10 @@ def main():
                 "BASELINE config 5, streaming replan with %d frames in flight (%d planner handles on the GPU take the frames in "
                 "turn; every frame is the same fxjps_replan_frame call):" % (PIPE_FRAMES, PIPE_FRAMES))
             out["c5pipe"] = rp
+        txt = json.dumps(out, indent=1, sort_keys=True)  # (number lists on one line each)
+        txt = re.sub(r"\[\s+((?:-?\d+(?:\.\d+)?(?:e[+-]?\d+)?,\s+)*-?\d+(?:\.\d+)?(?:e[+-]?\d+)?)\s+\]", lambda m: "[" + re.sub(r"\s+", " ", m.group(1)) + "]", txt)
         with open(OUT, "w") as f:
-            json.dump(out, f, indent=1, sort_keys=True)
+            f.write(txt + "\n")
 
 
 if __name__ == "__main__":
