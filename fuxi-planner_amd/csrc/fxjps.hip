@@ -1514,7 +1514,7 @@ int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, co
     }
     if (out_kept_cells && kept_capacity < kept_base)
         return fail(h, FXJPS_E_ARG, "out_kept_cells holds %lld pairs, the paths have %lld", (long long)kept_capacity, (long long)kept_base);
-    int rc = FXJPS_OK;
+    int rc = [&]() -> int {
     for (auto& P : parts) {  // queue every device, then collect
         DevCtx& d = *P.d;
         HIPCHK(h, hipSetDevice(d.dev));
@@ -1553,6 +1553,12 @@ int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, co
         if (out_kept_cells && P.total > 0)
             HIPCHK(h, hipMemcpyAsync(out_kept_cells + 2 * kept_at[(size_t)(&P - parts.data())], d.d_wp_kept.p, (size_t)P.total * 2 * sizeof(int32_t),
                                      hipMemcpyDeviceToHost, d.stream));
+    }
+    return FXJPS_OK;
+    }();
+    if (rc) {  // copies of the devices in front of the failing one are still queued on the caller's buffers
+        drain_all(h);
+        return rc;
     }
     for (auto& P : parts) {
         if (hipSetDevice(P.d->dev) != hipSuccess || hipStreamSynchronize(P.d->stream) != hipSuccess) rc = fail(h, FXJPS_E_HIP, "waypoint kernel failed");
