@@ -136,6 +136,8 @@ struct DevCtx {
     DBuf<long long> d_wp_off;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_val, d_upd_chg;
+    DBuf<int> d_owner;        // [W][H], -1 at rest: which entry of an update list decides a cell it names several times
+    bool owner_ready = false;
     // what the cell updates since the last rebuild of the derived maps can have changed: the box, in padded
     // coordinates, of the updated cells and their neighbours; whether the component labels need the full relabelling (a
     // large update, or 64 small ones, which are united into the existing labels as they come: k_ccl_update)
@@ -320,6 +322,7 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     d.NS = (d.PH + 63) & ~63;
     d.LINES = std::max(d.PW, d.PH);
     d.WORDS = (std::max(d.PW, d.PH) + 63) / 64;
+    d.owner_ready = false;  // (the update lists' owner cells follow the grid's shape)
     d.tsh = 0;  // read-set tiles (streaming replan): at most 64 x 64 of them cover the grid
     while (((std::max(W, H) - 1) >> d.tsh) > 63) d.tsh++;
     HIPCHK(h, d.occ.ensure((size_t)W * H));
@@ -778,7 +781,7 @@ void drain_all(fxjps* h) {
 
 extern "C" {
 
-int fxjps_version(void) { return 200; }
+int fxjps_version(void) { return 300; }
 
 int fxjps_device_count(void) {
     int n = 0;
@@ -891,6 +894,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_upd_xy.release();
         d.d_upd_val.release();
         d.d_upd_chg.release();
+        d.d_owner.release();
         d.h_len.release();
         d.h_cells.release();
         d.h_cost.release();
@@ -1147,7 +1151,7 @@ namespace {
 // Queue the cell updates and the rebuild of the derived maps on every device's stream (no host wait).
 int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n, bool derive) {
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "cell update before fxjps_set_grid");
-    if (n < 0 || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
+    if (n < 0 || n > 0x7FFFFFF0ll || (n > 0 && (!xy || !val))) return fail(h, FXJPS_E_ARG, "bad update arrays");
     if (n == 0 && !(derive && h->maps_stale)) return FXJPS_OK;
     // the box of the cells of the list that lie on the grid
     int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
@@ -1185,9 +1189,15 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
         }
         if (n > 0) {
             HIPCHK(h, d.d_upd_chg.ensure((size_t)n));
+            if (!d.owner_ready) {  // (streaming callers only: allocated with the first update of a grid)
+                HIPCHK(h, d.d_owner.ensure((size_t)d.W * d.H));
+                HIPCHK(h, hipMemsetAsync(d.d_owner.p, 0xFF, (size_t)d.W * d.H * sizeof(int), d.stream));
+                d.owner_ready = true;
+            }
             const unsigned nbk = (unsigned)((n + 255) / 256);
+            hipLaunchKernelGGL(fx::k_update_claim, dim3(nbk), dim3(256), 0, d.stream, d.d_owner.p, d.W, d.H, d.d_upd_xy.p, (long long)n);
             hipLaunchKernelGGL(fx::k_update_cells, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p,
-                               (long long)n, d.d_upd_chg.p);
+                               (long long)n, d.d_upd_chg.p, d.d_owner.p);
             // the labels: a small update is united into them right away (the list is on the device now, not when the
             // maps are rebuilt); a large one, and every 64th small one, asks for the full relabelling
             static const long long small_max = getenv("FXJPS_CCL_SMALL") ? atoll(getenv("FXJPS_CCL_SMALL")) : 8192;  // (0: always relabel)

@@ -127,12 +127,14 @@ int fxjps_publish_map(fxjps_t* h, int8_t* out_data, int32_t* out_width, int32_t*
 int fxjps_set_grid_image(fxjps_t* h, const uint8_t* gray, int32_t rows, int32_t cols);
 int fxjps_snapshot_image(fxjps_t* h, uint8_t* out, int32_t channels, int32_t* out_rows, int32_t* out_cols);
 
-/* Streaming replan: set n cells (xy pairs) to val[i] (0 free / non-zero
- * obstacle) on the resident grid and rebuild the derived maps. */
+/* Streaming replan: set n cells (xy pairs) to val[i] (0 free / non-zero obstacle) on the resident grid and rebuild the
+ * derived maps -- only what the changed cells can reach (their box for the scan words, the rows and columns through it
+ * for the cell infos; small lists are united into the component labels).  Cells outside the grid are ignored; a cell
+ * named more than once takes the value of its last entry. */
 int fxjps_update_cells(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_t n);
 
 /* fxjps_update_cells without the rebuild of the derived maps: the updates are applied to the resident grid (calls are
- * applied in order; one update per cell within a call; xy / val are copied before the call returns, which it may do
+ * applied in order; a cell named more than once in a call takes its last entry; xy / val are copied before the call returns, which it may do
  * while the update is still queued on the device -- every reader of the grid, fxjps_get_grid included, is ordered
  * behind it) and the maps are rebuilt once by the next fxjps_update_cells, fxjps_plan_batch* or fxjps_replan_frame.  For hosts that hand a handle several frames' updates before it plans
  * again (fuxi_planner_amd.replan.FramePipeline; scripts/global_planner_st.py:15-25 delivers one map message per

@@ -148,6 +148,16 @@ def test_odd_update_lists_and_several_contexts(oracle):
         p3.update_cells(xy[ok], cur[xy[ok, 0], xy[ok, 1]])                               # the resident values again
         check_against_fresh(p3, q, cur, "no-op lists")
         gpu_vs_oracle(p3, oracle, cur, s, g, 2)
+        # cells named several times with different values: the last entry of the list decides (`grid[xs, ys] = vals`)
+        for rep in range(5):
+            cells = np.stack([rng.integers(0, 300, 60), rng.integers(0, 200, 60)], 1)
+            xy = cells[rng.integers(0, 60, 4000)].astype(np.int32)
+            val = rng.integers(0, 2, 4000).astype(np.uint8)
+            cur[xy[:, 0], xy[:, 1]] = val
+            p3.update_cells(xy, val, rebuild=rep % 2 == 0)
+        p3.update_cells(np.zeros((0, 2), np.int32), np.zeros(0, np.uint8))
+        assert np.array_equal(p3.get_grid(), cur)
+        check_against_fresh(p3, q, cur, "lists with duplicates")
         # a deferred update, then a new (smaller) grid: the old box is forgotten
         p3.update_cells(np.array([[290, 190]], np.int32), np.array([1], np.uint8), rebuild=False)
         cur = synth.synth_grid(90, 120, 3, 0.2)

@@ -92,7 +92,7 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
     for fr in range(17):
         n = int(rng.integers(0, 20))
         xy = np.stack([rng.integers(0, 12, n), rng.integers(0, 9, n)], 1).astype(np.int32)
-        xy = np.unique(xy, axis=0).astype(np.int32).reshape(-1, 2)  # (one update per cell within a frame)
+        xy = np.unique(xy, axis=0).astype(np.int32).reshape(-1, 2)  # ((one update per cell within a frame: not required any more))
         val = rng.integers(0, 2, len(xy)).astype(np.uint8)
         g[xy[:, 0], xy[:, 1]] = val
         frames.append((xy, val))
