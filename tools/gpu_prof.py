@@ -53,6 +53,9 @@ for nq in nqs:
         print("   duplicate nodes %.3f / batch, batches with one %.2f %%" % (c[45] / c[4], 100.0 * c[46] / c[4]), flush=True)
         print("   commit in detail, cycles / batch: stores + counts %.0f, classify %.0f, far append + R merge %.0f, M append %.0f" % (
             c[10] / c[4], c[60] / c[4], c[61] / c[4], c[62] / c[4]), flush=True)
+    if c[4] and c[51]:
+        print("   second rounds in %.1f %% of the batches: %.2f more nodes each; intruder on a diagonal ray %.1f %%; predictable before the table lines: unique candidate in %.1f %% of the batches, with known cell info %.1f %%, and right in %.1f %% of the second rounds" % (
+            100.0 * c[51] / c[4], c[52] / c[51], 100.0 * c[53] / c[51], 100.0 * c[54] / c[4], 100.0 * c[55] / c[4], 100.0 * c[56] / c[51]), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
