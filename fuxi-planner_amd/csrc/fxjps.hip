@@ -105,7 +105,10 @@ struct DevCtx {
     int share = 1;  // contexts of this handle on the same physical device (they split its memory and wavefront slots)
     size_t mem_total = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
+    uint32_t* solo_started = nullptr;   // signal memory: blocks of that launch that have started
+    bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_solo0 = nullptr, ev_solo1 = nullptr;
     // grid
     int W = 0, H = 0, PW = 0, PH = 0, NS = 0, LINES = 0, WORDS = 0, tsh = 0;
     DBuf<uint8_t> occ, nb8;
@@ -475,10 +478,34 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
     waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
     waves = std::min<uint32_t>(waves, c.nwaves);
+    // Wavefronts per CU.  A query is a chain of dependent pops, and a wavefront that shares its CU with fifteen others runs
+    // that chain more slowly than one that has the CU to itself (config 2, the long diagonal queries: 0.69 us per pop among
+    // the batch, 0.62 alone on a CU, 0.59 alone on the chip).  A batch lasts as long as its slowest query; when the batch is
+    // small enough for that to show (up to 32 768 queries: beyond, the rest of the batch outlasts every single query), the
+    // head of the longest-first order (`nsolo` queries) goes first, in a launch of its own on a second stream: ONE live
+    // wavefront per block and an LDS size that lets no second block onto the CU.  The batch's launch starts when every
+    // block of that one is on its CU (a stream wait on a counter the blocks bump) and fills the rest of the chip.
+    // Measured on config 2: 102 k -> 114 k plans/s with 8 .. 48 such queries, two live wavefronts per CU 110 k, four 107 k;
+    // on a 125 000-query batch 24 of them cost 1 - 2 %.  FXJPS_SOLO / FXJPS_SOLO_LIVE: measurement and test aids.
+    // FXJPS_SPREAD=n (off by default: measured on config 5, 1000 queries, no gain) spreads a batch of at most n queries
+    // per CU the same way.
+    uint32_t nsolo = (nrun <= 32768u && d.share * h->mem_div == 1) ? 16u : 0u, live_solo = 1, live_main = 0;
+    if (const char* e = getenv("FXJPS_SOLO")) nsolo = (uint32_t)std::max(0, atoi(e));
+    if (const char* e = getenv("FXJPS_SOLO_LIVE")) live_solo = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("FXJPS_SPREAD")) live_main = (uint32_t)std::max(0, atoi(e));
+    if (live_solo != 1u && live_solo != 2u && live_solo != 4u) live_solo = 4u;
+    if (live_main != 0u && live_main != 1u && live_main != 2u && live_main != 4u) live_main = 4u;
+    if (pool != 0 || track || d_order == nullptr || d.solo_started == nullptr || nrun < 4096u || nrun < 64u * nsolo ||
+        waves <= 2u * nsolo + (uint32_t)fx::WPB)
+        nsolo = 0;
+    nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
+    if (nsolo != 0u) waves = std::min<uint32_t>(waves, (c.nwaves - nsolo) & ~((uint32_t)fx::WPB - 1u));
+    if (pool != 0 || nsolo != 0u || (uint64_t)nrun > (uint64_t)d.n_cu * live_main || d.share * h->mem_div > 1) live_main = 0u;
     if (pool == 0) d.waves_used = waves;
-    HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, sizeof(unsigned int), d.stream));
-    const dim3 grid(waves / fx::WPB), block(fx::WAVE * fx::WPB);
-    DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u", pool, waves, nrun, c.log2_buckets, c.far_cap);
+    HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, 2 * sizeof(unsigned int), d.stream));
+    const dim3 block(fx::WAVE * fx::WPB);
+    DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u solo=%u x %u spread=%u", pool, waves, nrun, c.log2_buckets, c.far_cap, nsolo,
+        live_solo, live_main);
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
     // instantiations: heuristic x read-set recording (fxjps_replan_frame) x table indexed by the cell
     {
@@ -487,9 +514,42 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
                                           {fx::k_search<1, true, false>, fx::k_search<1, true, true>}},
                                          {{fx::k_search<2, false, false>, fx::k_search<2, false, true>},
                                           {fx::k_search<2, true, false>, fx::k_search<2, true, true>}}};
-        hipLaunchKernelGGL(kfn[hchoice == 1 ? 0 : 1][track ? 1 : 0][c.direct_ly > 0 ? 1 : 0], grid, block, 0, d.stream, A);
+        const KFn fn = kfn[hchoice == 1 ? 0 : 1][track ? 1 : 0][c.direct_ly > 0 ? 1 : 0];
+        static const size_t pad = 36u << 10;  // 66 .. 74 KB of the block's own + this: no second block fits the CU's 160 KB
+        if (nsolo != 0u || live_main != 0u) {
+            const int ki = (hchoice == 1 ? 0 : 4) + (track ? 2 : 0) + (c.direct_ly > 0 ? 1 : 0);
+            if (!d.lds_attr_done[ki]) {
+                HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+                d.lds_attr_done[ki] = true;
+            }
+        }
+        if (nsolo != 0u) {
+            SearchArgs B = A;
+            B.nrun = nsolo;
+            B.solo = live_solo;
+            B.wave_base = waves;
+            B.next = d.d_next.p + 1;
+            A.q0 = nsolo;
+            A.nrun = nrun - nsolo;
+            B.started = d.solo_started;
+            HIPCHK(h, hipStreamWriteValue32(d.stream, d.solo_started, 0u, 0));
+            HIPCHK(h, hipEventRecord(d.ev_solo0, d.stream));
+            HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_solo0, 0));
+            hipLaunchKernelGGL(fn, dim3(nsolo / live_solo), block, pad, d.stream_solo, B);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipEventRecord(d.ev_solo1, d.stream_solo));
+            // the batch's launch must not take the CUs first: it starts when every solo block is on its CU
+            HIPCHK(h, hipStreamWaitValue32(d.stream, d.solo_started, nsolo / live_solo, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        }
+        if (live_main != 0u) {
+            A.solo = live_main;
+            hipLaunchKernelGGL(fn, dim3(waves / live_main), block, pad, d.stream, A);
+        } else {
+            hipLaunchKernelGGL(fn, dim3(waves / fx::WPB), block, 0, d.stream, A);
+        }
+        HIPCHK(h, hipGetLastError());
+        if (nsolo != 0u) HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_solo1, 0));
     }
-    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(d.ev1, d.stream));
     d.launches++;
     return FXJPS_OK;
@@ -530,26 +590,29 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC / (uint32_t)(d.share * h->mem_div);  // every wavefront the chip can hold at once (this handle's share of them)
     full = std::max<uint32_t>(full & ~((uint32_t)fx::WPB - 1u), (uint32_t)fx::WPB);
     if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(fx::WPB, atoi(e)) & ~((uint32_t)fx::WPB - 1u);  // measurement aid
-    // Longest-processing-time-first: expansions grow with the start-goal distance (correlation 0.94
-    // on the config-2 workload), so far-apart queries are handed out first and the short ones fill
-    // the tail.  Counting sort on the Chebyshev distance, descending.
+    // Longest-processing-time-first: the time a query takes grows with the start-goal distance, so far-apart queries are
+    // handed out first and the short ones fill the tail.  The key is max(dx, dy) + min(dx, dy) / 2: on the config-2
+    // workload it correlates 0.95 with the time a query takes and 0.95 with its expansions (Chebyshev distance: 0.91 /
+    // 0.94; Manhattan: 0.94 / 0.92) -- the queries that end last are the long DIAGONAL ones, whose open lists are full of
+    // equal keys (fewer nodes committed per iteration).  Counting sort, descending.
     {
         const int32_t* S = starts + 2 * d.q0;
         const int32_t* G = goals + 2 * d.q0;
-        std::vector<uint32_t> head(8194, 0);
+        constexpr uint32_t KMAX = 3u * 8192u - 1u;
+        std::vector<uint32_t> head(KMAX + 3u, 0);
         d.h_order.resize((size_t)nq);
         auto key = [&](int64_t i) -> uint32_t {
             const int64_t dx = std::llabs((int64_t)S[2 * i] - G[2 * i]), dy = std::llabs((int64_t)S[2 * i + 1] - G[2 * i + 1]);
-            return (uint32_t)std::min<int64_t>(std::max(dx, dy), 8191);
+            return (uint32_t)std::min<int64_t>(2 * std::max(dx, dy) + std::min(dx, dy), (int64_t)KMAX);
         };
         const bool subset = d.mode == 2;  // streaming replan: only the queries whose read set was touched
         auto in = [&](int64_t i) -> bool { return !subset || d.h_sel[(size_t)i] != 0; };
         for (int64_t i = 0; i < nq; i++)
-            if (in(i)) head[8191 - key(i) + 1]++;
-        for (int k = 1; k < 8194; k++) head[k] += head[k - 1];
-        d.nrun = head[8193];
+            if (in(i)) head[KMAX - key(i) + 1]++;
+        for (uint32_t k = 1; k < KMAX + 3u; k++) head[k] += head[k - 1];
+        d.nrun = head[KMAX + 2u];
         for (int64_t i = 0; i < nq; i++)
-            if (in(i)) d.h_order[head[8191 - key(i)]++] = (uint32_t)i;
+            if (in(i)) d.h_order[head[KMAX - key(i)]++] = (uint32_t)i;
         HIPCHK(h, d.d_order.ensure((size_t)nq));
         if (d.nrun > 0)
             HIPCHK(h, hipMemcpyAsync(d.d_order.p, d.h_order.data(), (size_t)d.nrun * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
@@ -816,6 +879,17 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         hipError_t e = hipSetDevice(d.dev);
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d.dev);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
+        if (e == hipSuccess) {
+            int can = 0;
+            if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, d.dev) != hipSuccess || !can ||
+                hipExtMallocWithFlags((void**)&d.solo_started, 8, hipMallocSignalMemory) != hipSuccess) {
+                (void)hipGetLastError();
+                d.solo_started = nullptr;  // no solo launches on this device
+            }
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_solo0, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_solo1, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&d.ev0);
         if (e == hipSuccess) e = hipEventCreate(&d.ev1);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_upd, hipEventDisableTiming);
@@ -903,6 +977,10 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_upd_xy.release();
         d.h_upd_val.release();
         if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
+        if (d.solo_started) (void)hipFree(d.solo_started);
+        if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
+        if (d.ev_solo1) (void)hipEventDestroy(d.ev_solo1);
+        if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);
         if (d.stream) (void)hipStreamDestroy(d.stream);

@@ -300,6 +300,35 @@ def test_hashed_and_cell_indexed_tables(planner, oracle):
     planner.set_grid_occ(occ)
 
 
+def test_longest_queries_on_cus_of_their_own(planner, oracle):
+    """Batches of 4 096 .. 32 768 queries run the head of the longest-first order in a launch of its own (one live
+    wavefront per CU, beside the batch's launch; launch_search in fxjps.hip).  Same bytes with it off, on (the default),
+    wider, with two and four live wavefronts per block and on hashed tables; a 1 000-query batch spread over the CUs
+    (FXJPS_SPREAD) too.  The oracle checks the first 1 500 queries."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(1024, 1024, 1, 0.20)
+    s, g = synth.synth_queries(occ, 1, 6000)
+    planner.set_grid_occ(occ)
+    with with_env(FXJPS_SOLO=0):
+        base = {h: planner.plan_batch(s, g, h, 1024) for h in (2, 1)}
+    want = oracle_csr(oracle, occ, s[:1500], g[:1500], 2, 1024)
+    assert np.array_equal(base[2][0][:1501], want[0]) and np.array_equal(base[2][1][:want[0][-1]], want[1])
+    assert base[2][2][:1500].tobytes() == want[2].tobytes()
+    for env in ({}, dict(FXJPS_SOLO=64), dict(FXJPS_SOLO=40, FXJPS_SOLO_LIVE=2), dict(FXJPS_SOLO=92, FXJPS_SOLO_LIVE=4)):
+        with with_env(**env):
+            for h in (2, 1):
+                assert_same(planner.plan_batch(s, g, h, 1024), base[h])
+    with with_env(FXJPS_DIRECT=0, FXJPS_SOLO=24):
+        planner.set_grid_occ(occ)
+        assert_same(planner.plan_batch(s, g, 2, 1024), base[2])
+    planner.set_grid_occ(occ)
+    small = planner.plan_batch(s[:1000], g[:1000], 2, 1024)
+    for live in (4, 2, 1):
+        with with_env(FXJPS_SPREAD=live):
+            assert_same(planner.plan_batch(s[:1000], g[:1000], 2, 1024), small)
+            assert_same(planner.plan_batch(s[:200], g[:200], 2, 1024), planner.plan_batch(s[:200], g[:200], 2, 1024))
+
+
 def test_frames_in_flight(oracle):
     """FramePipeline: three planner handles on the GPU take the frames of a toggle stream in turn, each applying the
     updates of the frames the others planned.  Every frame's result is the oracle's answer on that frame's grid."""
