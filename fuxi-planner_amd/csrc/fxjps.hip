@@ -107,6 +107,7 @@ struct DevCtx {
     hipStream_t stream = nullptr;
     hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
     uint32_t* solo_started = nullptr;   // signal memory: blocks of that launch that have started
+    size_t cells_bound = 0;             // bytes the batch in progress may still allocate for its packed paths
     bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_solo0 = nullptr, ev_solo1 = nullptr;
     // grid
@@ -342,6 +343,16 @@ uint32_t ceil_log2(uint64_t v) {
     return l;
 }
 
+// Gives the memory of pool 0 back (a batch buffer did not fit beside it); the next batch sizes it again from what is free.
+void release_pool0(DevCtx& d) {
+    (void)hipStreamSynchronize(d.stream);
+    d.tables[0].release();
+    d.far[0].release();
+    d.wave_gen[0].release();
+    d.cfg[0] = ScratchCfg();
+    d.pool_clean[0] = false;
+}
+
 // Size the per-wavefront scratch.  pool 0: many wavefronts, tables sized for the
 // typical query; pool 1: few wavefronts, tables that cannot overflow.
 int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
@@ -394,15 +405,31 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     }
     c.far_cap = (c.far_cap + 7u) & ~7u;  // the u16 cell-info array behind the entries stays 16-byte granular
     const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
-    // Memory budget.  Pool 0 may take 60 % of the device; pool 1 (allocated while pool 0 stays resident) is sized
-    // from what is free right now plus what it already holds, so that the two pools share one budget.
-    size_t budget = (d.mem_total ? (size_t)(d.mem_total * 0.6) : ((size_t)64 << 30)) / (size_t)(d.share * h->mem_div);
-    if (pool == 1) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t held = d.tables[1].cap * sizeof(TEnt) + d.far[1].cap * sizeof(FarEnt);
-            budget = std::min(budget, (size_t)((free_b + held) * 0.9));
-        }
+    // Memory budget.  A handle that has the device to itself gives pool 0 up to 80 % of it, less what the batch still
+    // has to allocate behind the search (the packed paths: at most nq * max_len cells), the smallest retry pool and a
+    // margin -- on grids with hashed tables the number of resident wavefronts is what this budget buys, and the plans/s
+    // of config 3 follow it almost linearly (1 536 / 2 270 / 2 840 wavefronts: 5.2 k / 7.5 k / 8.7 k plans/s).  Handles
+    // that share a device keep to 60 % of their share.  Pool 1 (allocated while pool 0 stays resident) is sized from
+    // what is free right now plus what it already holds, so that the two pools share one budget.  A batch buffer that
+    // does not fit later takes the memory back (release_pool0 in run_shard).
+    const size_t div = (size_t)(d.share * h->mem_div);
+    double frac = div == 1 ? 0.8 : 0.6;
+    if (const char* e = getenv("FXJPS_POOL_FRAC")) frac = std::min(0.95, std::max(0.05, atof(e)));  // measurement aid
+    size_t budget = (d.mem_total ? (size_t)(d.mem_total * frac) : ((size_t)64 << 30)) / div;
+    size_t free_b = 0, total_b = 0;
+    const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (pool == 0 && div == 1 && have_info) {
+        const size_t held = d.tables[0].cap * sizeof(TEnt) + d.far[0].cap * sizeof(FarEnt);
+        const uint32_t l2r = std::max(ceil_log2(cells * 2 + 64), 12u);
+        const size_t retry_wave = ((size_t)1 << l2r) * sizeof(TEnt) + (size_t)((cells * 2 + 1024) * 9 / 8) * sizeof(FarEnt);
+        const size_t reserve = (size_t)fx::WPB * retry_wave + d.cells_bound + ((size_t)6 << 30);
+        const size_t avail = free_b + held;
+        budget = std::min(budget, avail > reserve ? avail - reserve : (size_t)0);
+        budget = std::max(budget, std::min((size_t)(d.mem_total * 0.25), avail / 2));  // (never below what a shared device would get)
+    }
+    if (pool == 1 && have_info) {
+        const size_t held = d.tables[1].cap * sizeof(TEnt) + d.far[1].cap * sizeof(FarEnt);
+        budget = std::min(budget, (size_t)((free_b + held) * 0.9));
     }
     if (const char* e = getenv("FXJPS_POOL_BUDGET_MB")) budget = std::min<size_t>(budget, (size_t)std::max(1, atoi(e)) << 20);  // test aid
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
@@ -572,7 +599,12 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     HIPCHK(h, d.d_goals.ensure((size_t)nq * 2));
     HIPCHK(h, d.d_len.ensure((size_t)nq));
     HIPCHK(h, d.d_cost.ensure((size_t)nq));
-    HIPCHK(h, d.d_path.ensure((size_t)nq * max_len));
+    d.cells_bound = (size_t)nq * (size_t)max_len * 2 * sizeof(int32_t);
+    if (d.d_path.ensure((size_t)nq * max_len) != hipSuccess) {  // the scratch pool of an earlier, smaller batch may be in the way
+        (void)hipGetLastError();
+        release_pool0(d);
+        HIPCHK(h, d.d_path.ensure((size_t)nq * max_len));
+    }
     HIPCHK(h, d.d_offsets.ensure((size_t)nq + 1));
     HIPCHK(h, d.d_next.ensure(4));
     HIPCHK(h, d.d_counters.ensure(64));
@@ -678,7 +710,11 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     const long long total = d.h_offsets.p[nq];
     DBG("scan done, %lld cells", total);
     if (total > 0) {
-        HIPCHK(h, d.d_cells.ensure((size_t)total * 2));
+        if (d.d_cells.ensure((size_t)total * 2) != hipSuccess) {  // (the search is over: its scratch can go)
+            (void)hipGetLastError();
+            release_pool0(d);
+            HIPCHK(h, d.d_cells.ensure((size_t)total * 2));
+        }
         HIPCHK(h, d.h_cells.ensure((size_t)total * 2));
         hipLaunchKernelGGL(fx::k_gather_paths, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, d.stream, d.d_path.p,
                            d.d_len.p, d.d_offsets.p, (long long)nq, max_len, d.d_cells.p, total);
