@@ -127,6 +127,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     status = None
     retried = reused = direct = 0
     waves = waves_short = 0
+    launches = 1
     lat = None
     if pipe is not None:  # frames in flight: submit them all, the pipeline hands each to the next free handle
         for f in [pipe.submit(*frames[i]) for i in range(warmup)]:
@@ -163,6 +164,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
             reused += tm["reused"]
             direct = tm.get("table_direct", 0)
             waves, waves_short = int(tm["waves"]), int(tm["waves_short"])
+            launches = int(tm.get("search_launches", 1))
         cx.sync()
         elapsed = time.perf_counter() - t0
         per_ctx = planner.timing_per_context()  # (of the last step)
@@ -200,7 +202,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         "grid_now": g_last if streaming else None, "occ": occ, "mpl": mpl,
         "kernel_ms": k_dev, "kernel_ms_per_device": k_all, "algo": algo, "achieved": achieved,
         "frac": achieved / HBM_PEAK_GBS if achieved else None, "retried": int(retried), "reused": reused, "direct": direct,
-        "waves": waves, "waves_short": waves_short, "wl": wl, "frames": frames,
+        "waves": waves, "waves_short": waves_short, "launches": launches, "wl": wl, "frames": frames,
         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and name not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
     }
     if streaming:
@@ -348,10 +350,14 @@ def main():
                          "frac": m["frac"], "traffic": traffic,
                          # (the instantiation rocprofv3 lists: heuristic, read-set recording, table indexed by the cell)
                          "kernel": m["kernel"],
-                         "kernel_ms": m["kernel_ms"], "algorithmic_bytes_per_launch": m["algo"],
+                         "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "algorithmic_bytes_per_launch": m["algo"],
                          "algorithmic_bytes_source": wl.get("algorithmic_bytes_source", "oracle literal mode, all queries (tools/algo_bytes.py)"),
                          "note": "graph search bound by scattered-request rate and instruction issue, not by bytes (DESIGN.md section 4); traffic: " + tnote},
         }
+        if m["launches"] == 2:
+            out["roofline"]["note"] = ("a step is TWO overlapping launches of this kernel (the 16 longest queries on CUs of their own, "
+                                       "the rest of the batch beside them): kernel_ms is the HIP-event time around both, algorithmic bytes are "
+                                       "the step's; " + out["roofline"]["note"])
         if m["streaming"]:
             out["config"].update({"frames_per_s": m["frames_per_s"], "target_frames_per_s": 60,
                                   "cells_sent_per_frame": m["cells_sent_per_frame"],

@@ -578,7 +578,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
         if (nsolo != 0u) HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_solo1, 0));
     }
     HIPCHK(h, hipEventRecord(d.ev1, d.stream));
-    d.launches++;
+    d.launches += nsolo != 0u ? 2 : 1;  // (the two launches overlap: the events span both)
     return FXJPS_OK;
 }
 

@@ -165,30 +165,26 @@ def test_config3_full(planner, oracle):
     assert np.array_equal(st > 0, same)
 
 
-def test_scratch_pool_gives_memory_back(oracle):
+def test_scratch_pool_gives_memory_back(planner, oracle):
     """On grids with hashed tables a lone handle lets the scratch pool take up to 80 % of the device (the resident
     wavefronts are what that memory buys).  A later batch whose path buffer does not fit beside it takes the memory
     back instead of failing: 4 000 config-3 queries (pool: some 3 000 wavefronts x 76 MB), then 1 000 000 start == goal
     queries with max_len 16 384 (a 65 GB path buffer), then the first batch again -- same bytes."""
-    import fuxi_planner_amd as fx
     from fuxi_planner_amd import synth
-    p = fx.Planner([0])
-    try:
-        occ = synth.synth_grid(4096, 4096, 2, 0.20)
-        p.set_grid_occ(occ)
-        s, g = synth.synth_queries(occ, 2, 4000)
-        first = p.plan_batch(s, g, 2, 4096)
-        w0 = p.timing()["waves"]
-        assert w0 >= 2400, w0  # (60 % of the device bought 2 270)
-        n = 1000000
-        ss = np.repeat(s[:1000], n // 1000, axis=0)
-        off, cells, cost, st = p.plan_batch(ss, ss, 2, 16384)
-        assert (st == 1).all() and (cost == 0.0).all() and np.array_equal(cells.reshape(-1, 2), ss)
-        assert_same(p.plan_batch(s, g, 2, 4096), first)
-        o = oracle_csr(oracle, occ, s[:300], g[:300], 2, 4096, nthreads=min(NTHREADS, 64))
-        assert np.array_equal(first[0][:301], o[0]) and np.array_equal(first[1][:o[0][-1]], o[1]) and first[2][:300].tobytes() == o[2].tobytes()
-    finally:
-        p.close()
+    p = planner
+    occ = synth.synth_grid(4096, 4096, 2, 0.20)
+    p.set_grid_occ(occ)
+    s, g = synth.synth_queries(occ, 2, 4000)
+    first = p.plan_batch(s, g, 2, 4096)
+    w0 = p.timing()["waves"]
+    assert w0 >= 2400, w0  # (60 % of the device bought 2 270)
+    n = 1000000
+    ss = np.repeat(s[:1000], n // 1000, axis=0)
+    off, cells, cost, st = p.plan_batch(ss, ss, 2, 16384)
+    assert (st == 1).all() and (cost == 0.0).all() and np.array_equal(cells.reshape(-1, 2), ss)
+    assert_same(p.plan_batch(s, g, 2, 4096), first)
+    o = oracle_csr(oracle, occ, s[:300], g[:300], 2, 4096, nthreads=min(NTHREADS, 64))
+    assert np.array_equal(first[0][:301], o[0]) and np.array_equal(first[1][:o[0][-1]], o[1]) and first[2][:300].tobytes() == o[2].tobytes()
 
 
 # ------------------------------------------------------------------ config 5: streaming replan
