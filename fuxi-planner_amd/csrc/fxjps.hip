@@ -106,7 +106,8 @@ struct DevCtx {
     size_t mem_total = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
-    uint32_t* solo_started = nullptr;   // signal memory: blocks of that launch that have started
+    uint32_t* solo_started = nullptr;   // pinned host word: blocks of such launches that have started (only ever counts up)
+    uint32_t solo_target = 0;           // ... and how many have been launched
     size_t cells_bound = 0;             // bytes the batch in progress may still allocate for its packed paths
     bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_solo0 = nullptr, ev_solo1 = nullptr;
@@ -559,14 +560,20 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
             A.q0 = nsolo;
             A.nrun = nrun - nsolo;
             B.started = d.solo_started;
-            HIPCHK(h, hipStreamWriteValue32(d.stream, d.solo_started, 0u, 0));
             HIPCHK(h, hipEventRecord(d.ev_solo0, d.stream));
             HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_solo0, 0));
             hipLaunchKernelGGL(fn, dim3(nsolo / live_solo), block, pad, d.stream_solo, B);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(d.ev_solo1, d.stream_solo));
-            // the batch's launch must not take the CUs first: it starts when every solo block is on its CU
-            HIPCHK(h, hipStreamWaitValue32(d.stream, d.solo_started, nsolo / live_solo, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            // The batch's launch must not take the CUs first: it is queued when every block of this one has reported from
+            // its CU (a counter in pinned host memory; tens of microseconds).  The host waits, not the stream: a stream
+            // wait on a value only another queue's kernel can write deadlocks under tools that run one kernel at a time
+            // (rocprofv3 --pmc).  After 5 ms the batch goes ahead regardless -- placement is speed, never correctness.
+            d.solo_target += nsolo / live_solo;
+            const auto t0 = std::chrono::steady_clock::now();
+            while ((int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            }
         }
         if (live_main != 0u) {
             A.solo = live_main;
@@ -917,9 +924,9 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
         if (e == hipSuccess) {
-            int can = 0;
-            if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, d.dev) != hipSuccess || !can ||
-                hipExtMallocWithFlags((void**)&d.solo_started, 8, hipMallocSignalMemory) != hipSuccess) {
+            if (hipHostMalloc((void**)&d.solo_started, 64, hipHostMallocDefault) == hipSuccess) {
+                *d.solo_started = 0u;
+            } else {
                 (void)hipGetLastError();
                 d.solo_started = nullptr;  // no solo launches on this device
             }
@@ -1013,7 +1020,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_upd_xy.release();
         d.h_upd_val.release();
         if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
-        if (d.solo_started) (void)hipFree(d.solo_started);
+        if (d.solo_started) (void)hipHostFree(d.solo_started);
         if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
         if (d.ev_solo1) (void)hipEventDestroy(d.ev_solo1);
         if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
