@@ -190,7 +190,8 @@ int fxjps_last_cells(fxjps_t* h, int32_t* out_cells_xy, int64_t cells_capacity);
 typedef struct fxjps_timing {
     double search_kernel_ms; /* HIP-event time of the search kernel launches of the last batch */
     double total_ms;         /* wall time of the last batch call */
-    int64_t search_launches; /* kernel launches that made up search_kernel_ms */
+    int64_t search_launches; /* kernel launches that made up search_kernel_ms (a batch of 4 096 .. 32 768 queries is two
+                                overlapping launches: its longest queries on CUs of their own, the rest beside them) */
     int64_t retried;         /* queries re-run with large scratch */
     int64_t pops;            /* open-list pops executed by the last batch (all devices) */
     int64_t pushes;
