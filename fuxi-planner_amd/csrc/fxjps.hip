@@ -94,7 +94,8 @@ struct HBuf {  // grow-only pinned host buffer
 
 struct ScratchCfg {
     uint32_t nwaves = 0;
-    uint32_t log2_buckets = 0;
+    uint32_t nbuckets = 0;    // buckets per wavefront table (hashed: any number; cell-indexed: slots / BUCKET)
+    uint32_t usable = 0;      // hashed: entries a search may insert (3/4 of a full-size table, 7/8 of a shrunk one)
     uint32_t direct_ly = 0;  // > 0: the table is indexed by the cell (slot = x << direct_ly | y), see ensure_pool
     uint32_t far_cap = 0;
 };
@@ -360,6 +361,33 @@ void release_pool0(DevCtx& d) {
 int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     const uint64_t cells = (uint64_t)d.W * d.H;
     ScratchCfg c;
+    // Memory budget.  A handle that has the device to itself gives pool 0 up to 80 % of it, less what the batch still
+    // has to allocate behind the search (the packed paths: at most nq * max_len cells), the smallest retry pool and a
+    // margin -- on grids with hashed tables the number of resident wavefronts is what this budget buys, and the plans/s
+    // of config 3 follow it almost linearly (1 536 / 2 270 / 2 840 wavefronts: 5.2 k / 7.5 k / 8.7 k plans/s).  Handles
+    // that share a device keep to 60 % of their share.  Pool 1 (allocated while pool 0 stays resident) is sized from
+    // what is free right now plus what it already holds, so that the two pools share one budget.  A batch buffer that
+    // does not fit later takes the memory back (release_pool0 in run_shard).
+    const size_t div = (size_t)(d.share * h->mem_div);
+    double frac = div == 1 ? 0.8 : 0.6;
+    if (const char* e = getenv("FXJPS_POOL_FRAC")) frac = std::min(0.95, std::max(0.05, atof(e)));  // measurement aid
+    size_t budget = (d.mem_total ? (size_t)(d.mem_total * frac) : ((size_t)64 << 30)) / div;
+    size_t free_b = 0, total_b = 0;
+    const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    if (pool == 0 && div == 1 && have_info) {
+        const size_t held = d.tables[0].cap * sizeof(TEnt) + d.far[0].cap * sizeof(FarEnt);
+        const uint32_t l2r = std::max(ceil_log2(cells * 2 + 64), 12u);
+        const size_t retry_wave = ((size_t)1 << l2r) * sizeof(TEnt) + (size_t)((cells * 2 + 1024) * 9 / 8) * sizeof(FarEnt);
+        const size_t reserve = (size_t)fx::WPB * retry_wave + d.cells_bound + ((size_t)6 << 30);
+        const size_t avail = free_b + held;
+        budget = std::min(budget, avail > reserve ? avail - reserve : (size_t)0);
+        budget = std::max(budget, std::min((size_t)(d.mem_total * 0.25), avail / 2));  // (never below what a shared device would get)
+    }
+    if (pool == 1 && have_info) {
+        const size_t held = d.tables[1].cap * sizeof(TEnt) + d.far[1].cap * sizeof(FarEnt);
+        budget = std::min(budget, (size_t)((free_b + held) * 0.9));
+    }
+    if (const char* e = getenv("FXJPS_POOL_BUDGET_MB")) budget = std::min<size_t>(budget, (size_t)std::max(1, atoi(e)) << 20);  // test aid
     if (pool == 0) {
         // measured on the config-2 workload (1024^2, 20 %): a reachable query inserts 34 k nodes
         // on average, 117 k at p99, 139 k at most, and keeps at most 2.4 k entries open; a table
@@ -395,45 +423,45 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         }
         // test aids: force a small table / far tier so that the overflow -> large-pool retry paths run
         if (const char* e = getenv("FXJPS_TABLE_LOG2")) l2e = (uint32_t)std::min(std::max(atoi(e), 4), 23);
-        c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
-        c.far_cap = std::max<uint32_t>(2048u, ((uint32_t)fx::BUCKET << c.log2_buckets) / 8);
+        uint64_t entries = (uint64_t)1 << l2e;
+        c.usable = (uint32_t)(entries / 4 * 3);
+        // Hashed tables, and the wavefronts asked for do not fit the budget with them: the table shrinks, down to 3/4 of
+        // its size (then filled up to 7/8 instead of 3/4: 88 % of the entries it could hold before), as far as it takes
+        // to fit them.  The bucket count need not be a power of two (the hash is scaled to it).  Resident wavefronts are
+        // what the plans/s of such grids follow (config 3, 4096^2: 2 270 wavefronts of 76 MB 7.5 k plans/s, 3 000 9.0 k;
+        // the largest of its 100 000 queries inserts 2.42 M nodes, a shrunk table takes 2.75 M).  FXJPS_TABLE_SHRINK=0:
+        // measurement aid.
+        if (c.direct_ly == 0 && !getenv("FXJPS_TABLE_LOG2") && !(getenv("FXJPS_TABLE_SHRINK") && atoi(getenv("FXJPS_TABLE_SHRINK")) == 0)) {
+            const uint64_t want = std::max<uint64_t>((want_waves + 7u) & ~7u, (uint64_t)fx::WPB);
+            const double per_entry = (double)sizeof(TEnt) + (1.0 + 1.0 / 8) * sizeof(FarEnt) / 8.0;
+            const ScratchCfg& have = d.cfg[0];
+            if (have.nbuckets != 0u && have.direct_ly == 0u && have.nwaves >= want) {
+                // (the pool in place serves this batch: its size stays -- sizes that follow the free memory of the
+                // moment would have the pool allocated and wiped again and again)
+                entries = (uint64_t)have.nbuckets * (uint64_t)fx::BUCKET;
+                c.usable = have.usable;
+            } else if ((double)want * (double)entries * per_entry > (double)budget) {
+                uint64_t fit = (uint64_t)((double)budget / ((double)want * per_entry));
+                fit = std::max<uint64_t>(fit, entries / 4 * 3) & ~(uint64_t)(8 * fx::BUCKET - 1);
+                if (fit < entries) {
+                    entries = fit;
+                    c.usable = (uint32_t)(entries / 8 * 7);
+                }
+            }
+        }
+        c.nbuckets = (uint32_t)(entries / (uint64_t)fx::BUCKET);
+        c.far_cap = std::max<uint32_t>(2048u, (uint32_t)(entries / 8));
         if (const char* e = getenv("FXJPS_FAR_CAP")) c.far_cap = (uint32_t)std::min(std::max(atoi(e), 64), 1 << 24);
         c.nwaves = want_waves;
     } else {
         const uint32_t l2e = std::max(ceil_log2(cells * 2 + 64), 12u);
-        c.log2_buckets = l2e - fx::ceil_log2_c(fx::BUCKET);
+        c.nbuckets = (uint32_t)(((uint64_t)1 << l2e) / (uint64_t)fx::BUCKET);
+        c.usable = (uint32_t)(((uint64_t)1 << l2e) / 4 * 3);
         c.far_cap = (uint32_t)std::min<uint64_t>(cells * 2 + 1024, 0x7FFFFFFFull);
         c.nwaves = want_waves;
     }
     c.far_cap = (c.far_cap + 7u) & ~7u;  // the u16 cell-info array behind the entries stays 16-byte granular
-    const size_t per_wave = ((size_t)fx::BUCKET << c.log2_buckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
-    // Memory budget.  A handle that has the device to itself gives pool 0 up to 80 % of it, less what the batch still
-    // has to allocate behind the search (the packed paths: at most nq * max_len cells), the smallest retry pool and a
-    // margin -- on grids with hashed tables the number of resident wavefronts is what this budget buys, and the plans/s
-    // of config 3 follow it almost linearly (1 536 / 2 270 / 2 840 wavefronts: 5.2 k / 7.5 k / 8.7 k plans/s).  Handles
-    // that share a device keep to 60 % of their share.  Pool 1 (allocated while pool 0 stays resident) is sized from
-    // what is free right now plus what it already holds, so that the two pools share one budget.  A batch buffer that
-    // does not fit later takes the memory back (release_pool0 in run_shard).
-    const size_t div = (size_t)(d.share * h->mem_div);
-    double frac = div == 1 ? 0.8 : 0.6;
-    if (const char* e = getenv("FXJPS_POOL_FRAC")) frac = std::min(0.95, std::max(0.05, atof(e)));  // measurement aid
-    size_t budget = (d.mem_total ? (size_t)(d.mem_total * frac) : ((size_t)64 << 30)) / div;
-    size_t free_b = 0, total_b = 0;
-    const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-    if (pool == 0 && div == 1 && have_info) {
-        const size_t held = d.tables[0].cap * sizeof(TEnt) + d.far[0].cap * sizeof(FarEnt);
-        const uint32_t l2r = std::max(ceil_log2(cells * 2 + 64), 12u);
-        const size_t retry_wave = ((size_t)1 << l2r) * sizeof(TEnt) + (size_t)((cells * 2 + 1024) * 9 / 8) * sizeof(FarEnt);
-        const size_t reserve = (size_t)fx::WPB * retry_wave + d.cells_bound + ((size_t)6 << 30);
-        const size_t avail = free_b + held;
-        budget = std::min(budget, avail > reserve ? avail - reserve : (size_t)0);
-        budget = std::max(budget, std::min((size_t)(d.mem_total * 0.25), avail / 2));  // (never below what a shared device would get)
-    }
-    if (pool == 1 && have_info) {
-        const size_t held = d.tables[1].cap * sizeof(TEnt) + d.far[1].cap * sizeof(FarEnt);
-        budget = std::min(budget, (size_t)((free_b + held) * 0.9));
-    }
-    if (const char* e = getenv("FXJPS_POOL_BUDGET_MB")) budget = std::min<size_t>(budget, (size_t)std::max(1, atoi(e)) << 20);  // test aid
+    const size_t per_wave = ((size_t)fx::BUCKET * c.nbuckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
     constexpr uint32_t WPBm = (uint32_t)fx::WPB - 1u;  // wavefront counts are whole blocks
     maxw &= ~WPBm;
@@ -441,7 +469,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     if (((c.nwaves + WPBm) & ~WPBm) > maxw) d.waves_short = true;
     c.nwaves = std::max((uint32_t)fx::WPB, std::min((c.nwaves + WPBm) & ~WPBm, maxw));
     ScratchCfg& cur = d.cfg[pool];
-    const bool same = cur.log2_buckets == c.log2_buckets && cur.direct_ly == c.direct_ly && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
+    const bool same = cur.nbuckets == c.nbuckets && cur.usable == c.usable && cur.direct_ly == c.direct_ly && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
     if (same && d.pool_clean[pool]) return FXJPS_OK;
     if (!same) {
         // the old buffers die inside ensure(): forget the old configuration first, so that a failed allocation can
@@ -449,7 +477,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         cur = ScratchCfg();
         d.pool_clean[pool] = false;
         for (;;) {  // on out-of-memory run with fewer resident wavefronts instead of failing the batch
-            hipError_t e = d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET << c.log2_buckets));
+            hipError_t e = d.tables[pool].ensure((size_t)c.nwaves * ((size_t)fx::BUCKET * c.nbuckets));
             if (e == hipSuccess) e = d.far[pool].ensure((size_t)c.nwaves * (c.far_cap + c.far_cap / 8));
             if (e == hipSuccess) e = d.wave_gen[pool].ensure((size_t)c.nwaves);
             if (e == hipSuccess) break;
@@ -465,7 +493,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         cur = c;
     }
     // tables must start all-empty (key 0xFFFFFFFF); wavefronts leave them clean after each query
-    HIPCHK(h, hipMemsetAsync(d.tables[pool].p, 0xFF, (size_t)cur.nwaves * ((size_t)fx::BUCKET << cur.log2_buckets) * sizeof(TEnt),
+    HIPCHK(h, hipMemsetAsync(d.tables[pool].p, 0xFF, (size_t)cur.nwaves * ((size_t)fx::BUCKET * cur.nbuckets) * sizeof(TEnt),
                              d.stream));
     HIPCHK(h, hipMemsetAsync(d.wave_gen[pool].p, 0, (size_t)cur.nwaves * sizeof(uint32_t), d.stream));
     d.pool_clean[pool] = true;
@@ -489,7 +517,8 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.qread = track ? d.d_qread.p : nullptr;
     A.tables = d.tables[pool].p;
     A.far = d.far[pool].p;
-    A.log2_buckets = c.log2_buckets;
+    A.nbuckets = c.nbuckets;
+    A.tab_usable = c.usable;
     A.direct_ly = c.direct_ly;
     // The far band of the open list in f bands that a refill takes whole (no scan, no compaction): pays where open lists
     // hold thousands of entries (4096^2: + 10 %), costs where they hold hundreds (1024^2: - 10 %, an LDS atomic and a
@@ -533,7 +562,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     if (pool == 0) d.waves_used = waves;
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, 2 * sizeof(unsigned int), d.stream));
     const dim3 block(fx::WAVE * fx::WPB);
-    DBG("launch k_search pool=%d waves=%u nrun=%u log2b=%u far_cap=%u solo=%u x %u spread=%u", pool, waves, nrun, c.log2_buckets, c.far_cap, nsolo,
+    DBG("launch k_search pool=%d waves=%u nrun=%u buckets=%u far_cap=%u solo=%u x %u spread=%u", pool, waves, nrun, c.nbuckets, c.far_cap, nsolo,
         live_solo, live_main);
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
     // instantiations: heuristic x read-set recording (fxjps_replan_frame) x table indexed by the cell
