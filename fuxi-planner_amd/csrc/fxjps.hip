@@ -577,8 +577,13 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
         if (nsolo != 0u || live_main != 0u) {
             const int ki = (hchoice == 1 ? 0 : 4) + (track ? 2 : 0) + (c.direct_ly > 0 ? 1 : 0);
             if (!d.lds_attr_done[ki]) {
-                HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-                d.lds_attr_done[ki] = true;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad) == hipSuccess) {
+                    d.lds_attr_done[ki] = true;
+                } else {  // no such launches on this device then: the batch runs as one launch (speed, not correctness)
+                    (void)hipGetLastError();
+                    nsolo = 0u;
+                    live_main = 0u;
+                }
             }
         }
         if (nsolo != 0u) {
