@@ -541,8 +541,8 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     // the batch, 0.62 alone on a CU, 0.59 alone on the chip).  A batch lasts as long as its slowest query; when the batch is
     // small enough for that to show (up to 32 768 queries: beyond, the rest of the batch outlasts every single query), the
     // head of the longest-first order (`nsolo` queries) goes first, in a launch of its own on a second stream: ONE live
-    // wavefront per block and an LDS size that lets no second block onto the CU.  The batch's launch starts when every
-    // block of that one is on its CU (a stream wait on a counter the blocks bump) and fills the rest of the chip.
+    // wavefront per block and an LDS size that lets no second block onto the CU.  The batch's launch is queued when every
+    // block of that one has reported from its CU (a counter in pinned memory the host waits on) and fills the rest of the chip.
     // Measured on config 2: 102 k -> 114 k plans/s with 8 .. 48 such queries, two live wavefronts per CU 110 k, four 107 k;
     // on a 125 000-query batch 24 of them cost 1 - 2 %.  FXJPS_SOLO / FXJPS_SOLO_LIVE: measurement and test aids.
     // FXJPS_SPREAD=n (off by default: measured on config 5, 1000 queries, no gain) spreads a batch of at most n queries
