@@ -319,6 +319,13 @@ def test_hashed_and_cell_indexed_tables(planner, oracle):
             for h in (2, 1):
                 assert_same(planner.plan_batch(s, g, h, mpl), want[h])
             assert planner.timing()["table_direct"] == 0
+        if W == 1024:  # ... and hashed tables shrunk to fit the wavefronts: a bucket count that is no power of two
+            with with_env(FXJPS_DIRECT=0, FXJPS_POOL_BUDGET_MB=40000):
+                planner.set_grid_occ(occ)
+                for h in (2, 1):
+                    assert_same(planner.plan_batch(s, g, h, mpl), want[h])
+                tm = planner.timing()
+                assert tm["table_direct"] == 0 and tm["waves_short"] == 0 and tm["retried"] == 0, tm
     planner.set_grid_occ(occ)
 
 
