@@ -358,6 +358,41 @@ def test_longest_queries_on_cus_of_their_own(planner, oracle):
             assert_same(planner.plan_batch(s[:200], g[:200], 2, 1024), planner.plan_batch(s[:200], g[:200], 2, 1024))
 
 
+def test_head_launch_on_other_maps(planner, oracle):
+    """The head launch and the longest-first key on maps that are not config 2's: rooms with doors, blobs, a maze, an
+    empty map, a dense one -- batches of 4 096 .. 5 000 queries (the head launch runs), both heuristics, every query
+    against the oracle; queries with the start or the goal outside or on an obstacle among them."""
+    rng = np.random.default_rng(77)
+    maps = []
+    W, H = 640, 600
+    occ = np.zeros((W, H), np.uint8); occ[::23, :] = 1; occ[:, ::19] = 1
+    occ[(rng.random((W, H)) < 0.15) & (occ == 1)] = 0
+    maps.append(("rooms", occ))
+    occ = np.zeros((700, 520), np.uint8)
+    for _ in range(60):
+        x, y, r = int(rng.integers(0, 700)), int(rng.integers(0, 520)), int(rng.integers(2, 25))
+        occ[max(0, x - r):x + r, max(0, y - r):y + r] = 1
+    maps.append(("blobs", occ))
+    occ = np.ones((401, 401), np.uint8); occ[1::2, 1::2] = 0
+    occ[(rng.random((401, 401)) < 0.6) & ((np.add.outer(np.arange(401), np.arange(401)) % 2) == 1)] = 0
+    maps.append(("maze", occ))
+    maps.append(("open", np.zeros((512, 512), np.uint8)))
+    maps.append(("dense", (rng.random((600, 600)) < 0.40).astype(np.uint8)))
+    for name, occ in maps:
+        W, H = occ.shape
+        n = int(rng.integers(4096, 5001))
+        free = np.argwhere(occ == 0)
+        s = free[rng.integers(0, len(free), n)].astype(np.int32)
+        g = free[rng.integers(0, len(free), n)].astype(np.int32)
+        k = n // 50  # a few goals anywhere, outside the grid included
+        g[:k] = np.stack([rng.integers(-1, W + 1, k), rng.integers(-1, H + 1, k)], 1)
+        planner.set_grid_occ(occ)
+        for h in (2, 1):
+            got = planner.plan_batch(s, g, h, 4096)
+            assert planner.timing()["search_launches"] == 2, (name, planner.timing())
+            assert_same(got, oracle_csr(oracle, occ, s, g, h, 4096))
+
+
 def test_frames_in_flight(oracle):
     """FramePipeline: three planner handles on the GPU take the frames of a toggle stream in turn, each applying the
     updates of the frames the others planned.  Every frame's result is the oracle's answer on that frame's grid."""
