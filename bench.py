@@ -275,6 +275,8 @@ def main():
     else:
         devs = [cx.dev_index]
     cx.planner = fx.Planner(devs)
+    if cx.world > 1 and backend == "gloo":
+        cx.planner.set_memory_share(cx.world)  # (the rehearsal's ranks share device 0: a host that does that says so)
     if cx.world > 1:
         cx.sp = ShardedPlanner(cx.planner, device=cx.tdev)
 
