@@ -124,6 +124,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         return status, planner.timing()
 
     kernel_ms, per_ctx = [], None
+    head_ms, batch_ms = [], []
     status = None
     retried = reused = direct = 0
     waves = waves_short = 0
@@ -145,7 +146,8 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
             raise SystemExit("bench: queries failed")
         status = res[-1][3]  # (the last frame's: the CPU baseline below plans on that frame's grid)
         direct = 1
-        kernel_ms = [elapsed / steps * 1e3]  # (the launches of the frames overlap: the frame period stands in)
+        kernel_ms = [float("nan")]  # (the launches of the frames overlap: there is no kernel time; see frame_period_ms)
+        frame_period_ms = elapsed / steps * 1e3
         time.sleep(0.02)
         lat = np.array([(t_done[i] - t_sub[i]) * 1e3 for i in range(steps) if i in t_done])
         tm = [p.timing() for p in pipe.planners]
@@ -165,10 +167,14 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
             direct = tm.get("table_direct", 0)
             waves, waves_short = int(tm["waves"]), int(tm["waves_short"])
             launches = int(tm.get("search_launches", 1))
+            head_ms.append(tm.get("head_launch_ms", 0.0))
+            batch_ms.append(tm.get("batch_launch_ms", 0.0))
         cx.sync()
         elapsed = time.perf_counter() - t0
         per_ctx = planner.timing_per_context()  # (of the last step)
     k_ms = float(np.mean(kernel_ms))
+    if pipe is not None:
+        k_ms = None
     k_all = [k_ms]
     if cx.world > 1:
         t = cx.torch.tensor([elapsed, k_ms], dtype=cx.torch.float64, device=cx.tdev)
@@ -194,7 +200,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     else:  # weak: each device plans exactly the committed workload; strong: the mean shard
         algo = float(wl["algorithmic_bytes"]) / (n_units if strong else 1)
     k_dev = max(k_all) if (cx.inlib and cx.gpus > 1) else k_ms  # the kernel time the algorithmic bytes of ONE device go against
-    achieved = algo / (k_dev * 1e-3) / 1e9 if algo else None
+    achieved = algo / (k_dev * 1e-3) / 1e9 if (algo and k_dev) else None
     out = {
         "workload": name, "W": W, "H": H, "hchoice": hchoice, "streaming": streaming, "strong": strong,
         "describe": wl["describe"], "value": total_q * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
@@ -203,6 +209,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         "kernel_ms": k_dev, "kernel_ms_per_device": k_all, "algo": algo, "achieved": achieved,
         "frac": achieved / HBM_PEAK_GBS if achieved else None, "retried": int(retried), "reused": reused, "direct": direct,
         "waves": waves, "waves_short": waves_short, "launches": launches, "wl": wl, "frames": frames,
+        "launch_ms": ({"head": float(np.mean(head_ms)), "batch": float(np.mean(batch_ms))} if launches == 2 and head_ms else None),
         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and name not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
     }
     if streaming:
@@ -210,6 +217,10 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         out["cells_sent_per_frame"] = int(len(frames[0][1]))
         out["results_reused_per_frame"] = reused / steps
     if pipe is not None:
+        out["frame_period_ms"] = frame_period_ms
+        # (what the frames' overlapping launches move per second: algorithmic bytes per frame / frame period -- a rate of
+        # the pipeline, not of a kernel)
+        out["pipeline_GBps"] = algo / (frame_period_ms * 1e-3) / 1e9 if algo else None
         out["frames_in_flight"] = int(wl["frames_in_flight"])
         out["latency_ms"] = {"mean": float(lat.mean()), "p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                              "max": float(lat.max()), "frames": int(len(lat))}
@@ -228,6 +239,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="default workload: skip the config.also measurements")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe: planner handles taking the frames in turn (0: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
+    ap.add_argument("--py-sample", type=int, default=64, help="queries timed with the pure-Python restatement of the reference (0: none)")
     a = ap.parse_args()
     d_steps, d_warm = DEFAULT_STEPS.get(a.workload, (5, 2))
     a.steps = d_steps if a.steps is None else a.steps
@@ -304,6 +316,11 @@ def main():
             r = measure(cx, "c4shard", 2, 1)
             if r:
                 also["c4shard"] = brief(r)
+            if cx.world == 1:
+                r = measure(cx, "c3", 1, 0)  # BASELINE config 3: one timed step (100 000 queries on 4096^2, ~ 10 s), no warm-up
+                if r:
+                    also["c3"] = brief(r, ("retried",))
+                    also["c3"]["resident_wavefronts"] = r["waves"]
         else:
             r = measure(cx, "c4", 2, 1)  # the 1 M queries of BASELINE config 4 split N ways: the strong-scaling workload
             if r:
@@ -352,14 +369,15 @@ def main():
                          "frac": m["frac"], "traffic": traffic,
                          # (the instantiation rocprofv3 lists: heuristic, read-set recording, table indexed by the cell)
                          "kernel": m["kernel"],
-                         "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "algorithmic_bytes_per_launch": m["algo"],
+                         "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches"], "launch_ms": m["launch_ms"],
+                         "algorithmic_bytes_per_step": m["algo"],
                          "algorithmic_bytes_source": wl.get("algorithmic_bytes_source", "oracle literal mode, all queries (tools/algo_bytes.py)"),
                          "note": "graph search bound by scattered-request rate and instruction issue, not by bytes (DESIGN.md section 4); traffic: " + tnote},
         }
         if m["launches"] == 2:
             out["roofline"]["note"] = ("a step is TWO overlapping launches of this kernel (the 16 longest queries on CUs of their own, "
-                                       "the rest of the batch beside them): kernel_ms is the HIP-event time around both, algorithmic bytes are "
-                                       "the step's; " + out["roofline"]["note"])
+                                       "the rest of the batch beside them): kernel_ms is the HIP-event time around both, launch_ms that of "
+                                       "each, algorithmic bytes are the step's; " + out["roofline"]["note"])
         if m["streaming"]:
             out["config"].update({"frames_per_s": m["frames_per_s"], "target_frames_per_s": 60,
                                   "cells_sent_per_frame": m["cells_sent_per_frame"],
@@ -368,20 +386,24 @@ def main():
                 out["config"].update({"frames_in_flight": m["frames_in_flight"], "planner_handles": m["frames_in_flight"],
                                       "frame_latency_ms": m["latency_ms"]["mean"], "submit_to_paths_latency_ms": m["latency_ms"],
                                       "parallelism": "%d planner handles on one GPU take the frames in turn" % m["frames_in_flight"]})
-                out["roofline"]["note"] = "frames overlap: kernel_ms is the frame period; " + out["roofline"]["note"]
+                out["config"]["frame_period_ms"] = m["frame_period_ms"]
+                out["roofline"].update({"achieved": None, "frac": None, "kernel_ms": None, "pipeline_GBps": m["pipeline_GBps"]})
+                out["roofline"]["note"] = ("the launches of the frames in flight overlap: there is no kernel time and no roofline fraction of a "
+                                           "kernel; pipeline_GBps = algorithmic bytes per frame / frame period; " + out["roofline"]["note"])
         if a.workload == "c2" and not a.no_also and a.gpus == 1 and cx.world == 1:
             # config 5 with frames in flight, in a child process of its own (its eight handles want their own hardware
             # queues -- an environment variable the HIP runtime reads when it starts -- and their own memory)
             cx.planner.close()
             cx.planner = None
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c5pipe", "--steps", "64", "--warmup", "16",
-                                    "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c5pipe", "--no-cpu-baseline"],  # (its 600 frames)
+                                   capture_output=True, text=True, timeout=300)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 if r.returncode == 0 and line:
                     j = json.loads(line[-1])
                     also["c5pipe"] = {"value": j["config"]["frames_per_s"], "unit": "frames/s", "target": 60, "steps": j["steps"],
-                                      "ms_per_step": j["ms_per_step"], "kernel_ms": j["roofline"]["kernel_ms"], "frac": j["roofline"]["frac"],
+                                      "frame_period_ms": j["config"]["frame_period_ms"], "kernel_ms": None, "frac": None,
+                                      "pipeline_GBps": j["roofline"]["pipeline_GBps"],
                                       "planner_handles": j["config"]["planner_handles"],
                                       "submit_to_paths_latency_ms": j["config"]["submit_to_paths_latency_ms"],
                                       "plans_per_s": j["value"]}
@@ -404,6 +426,22 @@ def main():
             out["cpu_baseline"] = {"value": ns / dt, "unit": "plans/s", "cores": nth, "kind": "port",
                                    "sample": "first %d queries of the same batch, oracle/jps_oracle.c (-O2), "
                                              "%d pthreads, %.1f s" % (ns, nth, dt)}
+            if not m["streaming"] and m["W"] * m["H"] <= (1 << 20):
+                # The reference's own cost structure (dicts, heapq, the O(|open|) membership scan of jps1.py:224) in pure
+                # Python -- oracle/jps_python.py, pinned bit for bit to the real jps1.py by tests/test_oracle_python.py: the
+                # reference file itself cannot travel to this box.  A fixed subset, one process per host core.
+                from oracle import jps_python
+                npy = min(a.py_sample, m["n_local"])
+                if npy > 0:
+                    nproc = min(os.cpu_count() or 1, npy)
+                    lens, _, wall, cpu_s = jps_python.timed_batch(m["occ"], m["starts"][:npy], m["goals"][:npy], m["hchoice"], nproc)
+                    assert lens == [max(int(v), 0) for v in m["status"][:npy]], "the Python restatement disagrees with the GPU on path lengths"
+                    out["cpu_baseline_python"] = {"value": npy / wall, "unit": "plans/s", "cores": nproc, "kind": "port",
+                                                  "per_core_plans_per_s": npy / cpu_s,
+                                                  "sample": "first %d queries of the same batch, oracle/jps_python.py (pure Python restatement with the "
+                                                            "reference's data structures: dict / heapq / list scan of jps1.py:224), one process per core on "
+                                                            "%d of the host's %d hardware threads, %.1f s wall, %.1f s summed over the processes"
+                                                            % (npy, nproc, os.cpu_count() or 1, wall, cpu_s)}
         print(json.dumps(out), flush=True)
     if cx.world > 1:
         cx.dist.destroy_process_group()

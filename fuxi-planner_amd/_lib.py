@@ -15,7 +15,7 @@ BACKEND_HIP = 1
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
 SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
-           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask", "fxjps_debug_read_maps",
+           "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask", "fxjps_debug_read_maps", "fxjps_debug_counters", "fxjps_debug_qstat",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst", "fxjps_waypoint_ccst_batch", "fxjps_waypoint_st_batch")
 
 
@@ -23,7 +23,8 @@ class Timing(C.Structure):
     _fields_ = [("search_kernel_ms", C.c_double), ("total_ms", C.c_double), ("search_launches", C.c_int64),
                 ("retried", C.c_int64), ("pops", C.c_int64), ("pushes", C.c_int64), ("far_refills", C.c_int64),
                 ("slow_pops", C.c_int64), ("table_wipes", C.c_int64), ("reused", C.c_int64), ("table_direct", C.c_int64),
-                ("waves", C.c_int64), ("waves_short", C.c_int64)]
+                ("waves", C.c_int64), ("waves_short", C.c_int64), ("head_launch_ms", C.c_double), ("batch_launch_ms", C.c_double),
+                ("solo_timeouts", C.c_int64)]
 
 
 class FxjpsError(RuntimeError):

@@ -109,9 +109,13 @@ struct DevCtx {
     hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
     uint32_t* solo_started = nullptr;   // pinned host word: blocks of such launches that have started (only ever counts up)
     uint32_t solo_target = 0;           // ... and how many have been launched
+    int solo_timeouts = 0;              // waits for that counter that ran into their 5 ms bound (3: no more head launches here)
     size_t cells_bound = 0;             // bytes the batch in progress may still allocate for its packed paths
     bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_solo0 = nullptr, ev_solo1 = nullptr;
+    hipEvent_t ev_hd0 = nullptr, ev_hd1 = nullptr, ev_bt0 = nullptr, ev_bt1 = nullptr;  // around the head launch / the batch's launch alone
+    bool had_solo = false;              // the last regular-pool launch was two launches
+    double head_ms = 0, batch_ms = 0;   // ... and how long each of them ran
     // grid
     int W = 0, H = 0, PW = 0, PH = 0, NS = 0, LINES = 0, WORDS = 0, tsh = 0;
     DBuf<uint8_t> occ, nb8;
@@ -553,7 +557,7 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     if (const char* e = getenv("FXJPS_SPREAD")) live_main = (uint32_t)std::max(0, atoi(e));
     if (live_solo != 1u && live_solo != 2u && live_solo != 4u) live_solo = 4u;
     if (live_main != 0u && live_main != 1u && live_main != 2u && live_main != 4u) live_main = 4u;
-    if (pool != 0 || track || d_order == nullptr || d.solo_started == nullptr || nrun < 4096u || nrun < 64u * nsolo ||
+    if (pool != 0 || track || d_order == nullptr || d.solo_started == nullptr || d.solo_timeouts >= 3 || nrun < 4096u || nrun < 64u * nsolo ||
         waves <= 2u * nsolo + (uint32_t)fx::WPB)
         nsolo = 0;
     nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
@@ -597,8 +601,10 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
             B.started = d.solo_started;
             HIPCHK(h, hipEventRecord(d.ev_solo0, d.stream));
             HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_solo0, 0));
+            HIPCHK(h, hipEventRecord(d.ev_hd0, d.stream_solo));
             hipLaunchKernelGGL(fn, dim3(nsolo / live_solo), block, pad, d.stream_solo, B);
             HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipEventRecord(d.ev_hd1, d.stream_solo));
             HIPCHK(h, hipEventRecord(d.ev_solo1, d.stream_solo));
             // The batch's launch must not take the CUs first: it is queued when every block of this one has reported from
             // its CU (a counter in pinned host memory; tens of microseconds).  The host waits, not the stream: a stream
@@ -607,9 +613,15 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
             d.solo_target += nsolo / live_solo;
             const auto t0 = std::chrono::steady_clock::now();
             while ((int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+                    // (the counter never arrived -- no PCIe atomics, a tool that serialises kernels: after three such
+                    // waits this device runs its batches as one launch; fxjps_timing_t::solo_timeouts says so)
+                    d.solo_timeouts++;
+                    break;
+                }
             }
         }
+        if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, d.stream));
         if (live_main != 0u) {
             A.solo = live_main;
             hipLaunchKernelGGL(fn, dim3(waves / live_main), block, pad, d.stream, A);
@@ -617,7 +629,11 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
             hipLaunchKernelGGL(fn, dim3(waves / fx::WPB), block, 0, d.stream, A);
         }
         HIPCHK(h, hipGetLastError());
-        if (nsolo != 0u) HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_solo1, 0));
+        if (nsolo != 0u) {
+            HIPCHK(h, hipEventRecord(d.ev_bt1, d.stream));
+            HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_solo1, 0));
+        }
+        if (pool == 0) d.had_solo = nsolo != 0u;
     }
     HIPCHK(h, hipEventRecord(d.ev1, d.stream));
     d.launches += nsolo != 0u ? 2 : 1;  // (the two launches overlap: the events span both)
@@ -636,6 +652,7 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
     d.nrun = 0;
     d.waves_used = 0;
     d.waves_short = false;
+    d.had_solo = false;
     if (nq == 0) return FXJPS_OK;
     HIPCHK(h, d.d_starts.ensure((size_t)nq * 2));
     HIPCHK(h, d.d_goals.ensure((size_t)nq * 2));
@@ -717,9 +734,17 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     HIPCHK(h, hipStreamSynchronize(d.stream));
     DBG("search kernel done");
     float ms = 0;
+    d.head_ms = d.batch_ms = 0;
     if (d.launches > 0) {
         HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
         d.kernel_ms += ms;
+        if (d.had_solo) {
+            float a = 0, b = 0;
+            HIPCHK(h, hipEventElapsedTime(&a, d.ev_hd0, d.ev_hd1));
+            HIPCHK(h, hipEventElapsedTime(&b, d.ev_bt0, d.ev_bt1));
+            d.head_ms = a;
+            d.batch_ms = b;
+        }
     }
     std::vector<uint32_t> redo;
     for (int64_t i = 0; i < nq; i++)
@@ -782,6 +807,9 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
         return fail(h, FXJPS_E_ARG, "hchoice must be 1 or 2 (the reference raises TypeError, jps1.py:188)");
     if (max_len < 1 || max_len > (1 << 20)) return fail(h, FXJPS_E_ARG, "max_path_len out of range");
     if (nq > 0x7FFFFFF0ll) return fail(h, FXJPS_E_ARG, "too many queries in one batch");
+    // Until this batch is complete (emit_csr) no earlier batch is "the last batch": the resident-path forms of the
+    // waypoint entry points refuse with FXJPS_E_ARG instead of reading lengths and offsets of different batches.
+    h->last_nq = 0;
     if (h->maps_stale) {  // deferred cell updates: the maps are rebuilt once, in front of the search
         int rc = update_cells_async(h, nullptr, nullptr, 0, true);
         if (rc) return rc;
@@ -798,6 +826,7 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     for (int r = 0; r < nd && !rc; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
     if (rc) {
         drain_all(h);  // before the error leaves the library
+        for (auto& d : h->devs) d.nq = 0;  // (no shard holds a result)
         return rc;
     }
     fxjps_timing_t& T = h->timing;
@@ -813,7 +842,13 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     T.table_direct = 0;
     T.waves = 0;
     T.waves_short = 0;
+    T.head_launch_ms = 0;
+    T.batch_launch_ms = 0;
+    T.solo_timeouts = 0;
     for (auto& d : h->devs) {
+        T.head_launch_ms = std::max(T.head_launch_ms, d.head_ms);
+        T.batch_launch_ms = std::max(T.batch_launch_ms, d.batch_ms);
+        T.solo_timeouts += d.solo_timeouts;
         T.waves += d.waves_used;
         if (d.waves_short) T.waves_short = 1;
         T.search_kernel_ms = std::max(T.search_kernel_ms, d.kernel_ms);
@@ -962,7 +997,8 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
         if (e == hipSuccess) {
-            if (hipHostMalloc((void**)&d.solo_started, 64, hipHostMallocDefault) == hipSuccess) {
+            // (fine-grained, mapped: the kernel counts with a system-scope atomic, the host polls)
+            if (hipHostMalloc((void**)&d.solo_started, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
                 *d.solo_started = 0u;
             } else {
                 (void)hipGetLastError();
@@ -973,6 +1009,10 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_solo1, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&d.ev0);
         if (e == hipSuccess) e = hipEventCreate(&d.ev1);
+        if (e == hipSuccess) e = hipEventCreate(&d.ev_hd0);
+        if (e == hipSuccess) e = hipEventCreate(&d.ev_hd1);
+        if (e == hipSuccess) e = hipEventCreate(&d.ev_bt0);
+        if (e == hipSuccess) e = hipEventCreate(&d.ev_bt1);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_upd, hipEventDisableTiming);
         if (e != hipSuccess) {
             int rc = fail(nullptr, FXJPS_E_HIP, "device %d: %s", d.dev, hipGetErrorString(e));
@@ -1065,6 +1105,8 @@ void fxjps_destroy(fxjps_t* h) {
         if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);
+        for (hipEvent_t ev : {d.ev_hd0, d.ev_hd1, d.ev_bt0, d.ev_bt1})
+            if (ev) (void)hipEventDestroy(ev);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete h;
@@ -1602,10 +1644,19 @@ int fxjps_set_memory_share(fxjps_t* h, int32_t handles_per_device) {
     if (handles_per_device < 1 || handles_per_device > 64) return fail(h, FXJPS_E_ARG, "handles_per_device must be 1..64");
     if (h->mem_div != handles_per_device) {
         h->mem_div = handles_per_device;
-        for (auto& d : h->devs) {  // the next batch sizes its pools again
-            d.cfg[0] = ScratchCfg();
-            d.cfg[1] = ScratchCfg();
-            d.pool_clean[0] = d.pool_clean[1] = false;
+        for (auto& d : h->devs) {  // the next batch sizes its pools again -- from nothing: the buffers are grow-only, and
+                                   // a pool sized for the whole device would stay, and be credited to this handle's budget
+            if (hipSetDevice(d.dev) == hipSuccess) {
+                if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
+                (void)hipStreamSynchronize(d.stream);
+            }
+            for (int p = 0; p < 2; p++) {
+                d.tables[p].release();
+                d.far[p].release();
+                d.wave_gen[p].release();
+                d.cfg[p] = ScratchCfg();
+                d.pool_clean[p] = false;
+            }
         }
     }
     return FXJPS_OK;
@@ -1838,7 +1889,7 @@ int fxjps_selftest_sqrt(fxjps_t* h, uint32_t n0, uint32_t n1, double* out) {
 
 
 // raw device counters of the last batch on device 0: [0] pops [1] pushes [2] refills [3] slow pops,
-// [8..17] per-phase cycles in FXJPS_PROF builds (tools only; not declared in fxjps.h)
+// [8..17] per-phase cycles in FXJPS_PROF builds (tools only)
 int fxjps_debug_counters(fxjps_t* h, unsigned long long* out32) {
     if (!h || !out32) return FXJPS_E_ARG;
     DevCtx& d = h->devs[0];
@@ -1847,7 +1898,7 @@ int fxjps_debug_counters(fxjps_t* h, unsigned long long* out32) {
     return FXJPS_OK;
 }
 
-// per-query diagnostics of the last batch on device 0 (FXJPS_QSTAT=1): 4 u64 per query (tools only; not in fxjps.h)
+// per-query diagnostics of the last batch on device 0 (FXJPS_QSTAT=1): 4 u64 per query (tools only)
 int fxjps_debug_qstat(fxjps_t* h, unsigned long long* out, int64_t nq) {
     if (!h || !out) return FXJPS_E_ARG;
     DevCtx& d = h->devs[0];

@@ -204,6 +204,10 @@ typedef struct fxjps_timing {
     int64_t waves;           /* resident wavefronts (= queries in flight) the last batch ran with, summed over the contexts */
     int64_t waves_short;     /* 1: a scratch pool was granted fewer wavefronts than the batch asked for (memory budget of the
                                 handle, or the device ran out of memory): the batch ran, with less parallelism */
+    double head_launch_ms;   /* search_launches == 2: HIP-event time of the launch of the longest queries alone ... */
+    double batch_launch_ms;  /* ... and of the launch of the rest of the batch beside it (0 when the batch was one launch) */
+    int64_t solo_timeouts;   /* waits for the head launch's blocks to report from their CUs that ran into their 5 ms bound,
+                                since the handle was created (3 on a device: it runs its batches as one launch from then on) */
 } fxjps_timing_t;
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
 
@@ -257,6 +261,13 @@ int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
  * columns from H + 2 on are unused), 2 the component forest (int32 [W][H]: parent links, a root points at itself, -1
  * never free), 3 the neighbour bytes ([W + 2][NS]).  out_bytes receives the size; buf == NULL: the size only. */
 int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity_bytes, int64_t* out_bytes);
+
+/* Measurement aids of tools/ (not used by the planner's Python host code).  fxjps_debug_counters: the 64 raw device
+ * counters of the last batch on the first context ([0] pops, [1] pushes, [2] far refills, [3] slow pops, [7] table wipes;
+ * the rest is filled by the diagnostic build -DFXJPS_PROF only).  fxjps_debug_qstat: with FXJPS_QSTAT=1 in the
+ * environment, 4 u64 per query of the last batch on the first context: start, end (100 MHz ticks), pops, wavefront. */
+int fxjps_debug_counters(fxjps_t* h, unsigned long long* out64);
+int fxjps_debug_qstat(fxjps_t* h, unsigned long long* out, int64_t nq);
 
 /* ---- Waypoint selection after a plan.  One path per call, host functions (no device work, no handle;
  * the batch forms below take the grid from the handle and run the ccst pruning on the device):

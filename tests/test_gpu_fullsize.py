@@ -333,16 +333,17 @@ def test_longest_queries_on_cus_of_their_own(planner, oracle):
     """Batches of 4 096 .. 32 768 queries run the head of the longest-first order in a launch of its own (one live
     wavefront per CU, beside the batch's launch; launch_search in fxjps.hip).  Same bytes with it off, on (the default),
     wider, with two and four live wavefronts per block and on hashed tables; a 1 000-query batch spread over the CUs
-    (FXJPS_SPREAD) too.  The oracle checks the first 1 500 queries."""
+    (FXJPS_SPREAD) too.  The oracle checks the first 1 500 queries under both heuristics."""
     from fuxi_planner_amd import synth
     occ = synth.synth_grid(1024, 1024, 1, 0.20)
     s, g = synth.synth_queries(occ, 1, 6000)
     planner.set_grid_occ(occ)
     with with_env(FXJPS_SOLO=0):
         base = {h: planner.plan_batch(s, g, h, 1024) for h in (2, 1)}
-    want = oracle_csr(oracle, occ, s[:1500], g[:1500], 2, 1024)
-    assert np.array_equal(base[2][0][:1501], want[0]) and np.array_equal(base[2][1][:want[0][-1]], want[1])
-    assert base[2][2][:1500].tobytes() == want[2].tobytes()
+    for h in (2, 1):
+        want = oracle_csr(oracle, occ, s[:1500], g[:1500], h, 1024)
+        assert np.array_equal(base[h][0][:1501], want[0]) and np.array_equal(base[h][1][:want[0][-1]], want[1])
+        assert base[h][2][:1500].tobytes() == want[2].tobytes() and np.array_equal(base[h][3][:1500], want[3])
     for env in ({}, dict(FXJPS_SOLO=64), dict(FXJPS_SOLO=40, FXJPS_SOLO_LIVE=2), dict(FXJPS_SOLO=92, FXJPS_SOLO_LIVE=4)):
         with with_env(**env):
             for h in (2, 1):
@@ -415,6 +416,33 @@ def test_frames_in_flight(oracle):
         futs = [pipe.submit(xy, val) for xy, val in frames]
         for fr, f in enumerate(futs):
             assert_same(f.result(), want[fr])
+
+
+def test_frames_in_flight_config5_eight_handles(oracle):
+    """BASELINE config 5 the way bench.py --workload c5pipe runs it: 1024^2, the 1 000 persistent queries, 10 % of the cells
+    toggled per frame (SURVEY 8d stream), EIGHT planner handles taking the frames in turn -- 48 frames, every path of
+    every frame against the oracle on that frame's grid."""
+    import json
+    from fuxi_planner_amd import synth
+    from fuxi_planner_amd.replan import FramePipeline
+    with open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")) as f:
+        wl = json.load(f)["c5pipe"]
+    occ = synth.synth_grid(wl["W"], wl["H"], wl["grid_seed"], wl["p"])
+    s, g = synth.synth_queries(occ, wl["qseed"], wl["nq"])
+    keep = np.zeros(occ.shape, dtype=bool)
+    keep[s[:, 0], s[:, 1]] = True
+    keep[g[:, 0], g[:, 1]] = True
+    grid = occ.copy()
+    nframes = 48
+    frames = []
+    for fr in range(nframes):
+        xy, val = synth.frame_update(grid, keep, fr, wl)
+        synth.apply_toggles(grid, xy, val)
+        frames.append((xy, val, grid.copy()))
+    with FramePipeline(0, 8, occ, s, g, wl["hchoice"], wl["max_path_len"]) as pipe:
+        futs = [pipe.submit(xy, val) for xy, val, _ in frames]
+        for fr, f in enumerate(futs):
+            assert_same(f.result(), oracle_csr(oracle, frames[fr][2], s, g, wl["hchoice"], wl["max_path_len"]))
 
 
 def test_grid_of_6144_with_2_to_the_27_slot_tables(planner, oracle):
