@@ -274,6 +274,7 @@ GridDev grid_of(const DevCtx& d) {
     G.NS = d.NS;
     G.LINES = d.LINES;
     G.WORDS = d.WORDS;
+    G.DLINES = d.PW + d.PH - 1;
     G.tsh = d.tsh;
     return G;
 }
@@ -305,6 +306,13 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
             const long long ncell = (long long)d.PW * d.PH;
             hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p,
                                fx::MapRange{0, d.PW - 1, 0, d.PH - 1});
+        }
+        {  // the diagonal scan words: a function of the cell infos (and the occupancy) cell by cell -- of the cells above
+            const fx::DiagRange dr{box ? 0 : 1, d.bx0, d.bx1, d.by0, d.by1};
+            const long long per = box ? (long long)((d.bx1 >> 6) - (d.bx0 >> 6) + 1) + (((d.by1 - d.by0 + 63) >> 6) + 1) : (long long)d.WORDS;
+            const long long nw = 4ll * G.DLINES * per;
+            hipLaunchKernelGGL(fx::k_derive_diag, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G,
+                               d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
         }
         HIPCHK(h, hipGetLastError());
     }
@@ -339,7 +347,7 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     HIPCHK(h, d.comp.ensure((size_t)W * H));
     HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
     HIPCHK(h, d.ci.ensure((size_t)d.PW * d.NS));
-    HIPCHK(h, d.bm.ensure((size_t)4 * d.LINES * d.WORDS));
+    HIPCHK(h, d.bm.ensure((size_t)4 * d.LINES * d.WORDS + (size_t)4 * (d.PW + d.PH - 1) * d.WORDS));  // straight + diagonal scan lines
     return FXJPS_OK;
 }
 
@@ -2063,7 +2071,8 @@ int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity
         case 1: src = d.ci.p; bytes = (size_t)d.PW * d.NS * sizeof(uint16_t); break;               // cell infos [PW][NS] (columns >= PH unused)
         case 2: src = d.comp.p; bytes = (size_t)d.W * d.H * sizeof(int); break;                    // component forest [W][H]
         case 3: src = d.nb8.p; bytes = (size_t)d.PW * d.NS; break;                                 // neighbour bytes [PW][NS]
-        default: return fail(h, FXJPS_E_ARG, "which must be 0 .. 3");
+        case 4: src = d.bm.p + (size_t)4 * d.LINES * d.WORDS; bytes = (size_t)4 * (d.PW + d.PH - 1) * d.WORDS * sizeof(fx::BmWord); break;  // diagonal scan words
+        default: return fail(h, FXJPS_E_ARG, "which must be 0 .. 4");
     }
     if (out_bytes) *out_bytes = (int64_t)bytes;
     if (!buf) return FXJPS_OK;

@@ -317,7 +317,8 @@ class Planner(object):
 
     def debug_maps(self):
         """The derived device maps (fxjps_debug_read_maps): {"bm": uint64[4, LINES, WORDS, 2], "ci": uint16[W+2, H+2],
-        "comp": int32[W, H] (union-find parent links), "nb8": uint8[W+2, H+2]}."""
+        "comp": int32[W, H] (union-find parent links), "nb8": uint8[W+2, H+2], "dbm": uint64[4, W+H+3, WORDS, 2] (the
+        diagonal scan words)}."""
         W, H = self.shape
         PW, PH = W + 2, H + 2
         NS = (PH + 63) & ~63
@@ -325,7 +326,7 @@ class Planner(object):
         WORDS = (LINES + 63) // 64
         out = {}
         for which, name, dt, shape in ((0, "bm", np.uint64, (4, LINES, WORDS, 2)), (1, "ci", np.uint16, (PW, NS)), (2, "comp", np.int32, (W, H)),
-                                       (3, "nb8", np.uint8, (PW, NS))):
+                                       (3, "nb8", np.uint8, (PW, NS)), (4, "dbm", np.uint64, (4, PW + PH - 1, WORDS, 2))):
             a = np.zeros(shape, dtype=dt)
             nb = C.c_int64(0)
             self._chk(self._L.fxjps_debug_read_maps(self._h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.byref(nb)))

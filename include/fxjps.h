@@ -259,7 +259,9 @@ int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
  * cells can reach -- with those of a fresh upload): which = 0 the scan words ([4][LINES][WORDS] pairs of u64 {stop, occ},
  * LINES = max(W, H) + 2, WORDS = ceil(LINES / 64)), 1 the cell infos (u16 [W + 2][NS], NS = H + 2 rounded up to 64; the
  * columns from H + 2 on are unused), 2 the component forest (int32 [W][H]: parent links, a root points at itself, -1
- * never free), 3 the neighbour bytes ([W + 2][NS]).  out_bytes receives the size; buf == NULL: the size only. */
+ * never free), 3 the neighbour bytes ([W + 2][NS]), 4 the diagonal scan words ([4][W + H + 3][WORDS] pairs of u64 {stop, occ}:
+ * travel directions (+,+), (-,-), (+,-), (-,+), one line per diagonal, bit = padded x).  out_bytes receives the size;
+ * buf == NULL: the size only. */
 int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity_bytes, int64_t* out_bytes);
 
 /* Measurement aids of tools/ (not used by the planner's Python host code).  fxjps_debug_counters: the 64 raw device
