@@ -227,12 +227,83 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     return out
 
 
+def measure_c1(cx, reps=20):
+    """BASELINE config 1 and the node's real call: ONE query per call on the reference's own maps (tests/golden/maps_png.npz:
+    the 35 maps/*.png as the loader of global_planner_st.py:176-182 reads them).  The 147 x 112 map pasted into a zero
+    256 x 256 canvas with the three queries of SURVEY 8(c), and every map with its first-free -> last-free query.  Every
+    answer is checked (canvas: against the paths captured from the real jps1.py; maps: against the C oracle).  Microseconds
+    per call of Planner.plan on the resident grid and of the jps1.method drop-in (grid conversion + upload + map build +
+    search), beside the C port and the pure-Python restatement of the reference on one host core."""
+    import contextlib
+    import io
+    import fuxi_planner_amd as fx
+    from oracle import jps_python, oracle
+    z = np.load(os.path.join(ROOT, "tests", "golden", "maps_png.npz"))
+    with open(os.path.join(ROOT, "tests", "golden", "maps_png.json")) as f:
+        recs = json.load(f)
+    p = cx.planner
+
+    def timed(fn, n):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        return (time.perf_counter() - t0) / n * 1e6, r
+
+    name = "-16.20-11.40_out.png"
+    occ = np.zeros((256, 256), dtype=np.uint8)
+    occ[:147, :112] = np.unpackbits(z[name])[:147 * 112].reshape(147, 112)
+    m64 = occ.astype(np.float64)  # what the node passes (st:248)
+    canvas = []
+    p.set_grid_occ(occ)
+    for rec in [r for r in recs if r.get("canvas") and r["map"] == name][:3]:
+        s, g = tuple(rec["start"]), tuple(rec["goal"])
+        want = [tuple(rec["path"][i:i + 2]) for i in range(0, len(rec["path"]), 2)]
+        us, path = timed(lambda: p.plan(s, g, 2), reps)
+        assert path == want, "c1: the path differs from the one captured from jps1.py"
+        with contextlib.redirect_stdout(io.StringIO()):
+            us_m, r = timed(lambda: fx.jps1.method(m64, s, g, 2), reps)
+        assert r[0] == want
+        us_c, rc = timed(lambda: oracle.plan(occ, s, g, 2, literal=False), reps)
+        assert rc[0] == want
+        t0 = time.perf_counter()
+        rp = jps_python.search(m64, s, g, 2)
+        ms_py = (time.perf_counter() - t0) * 1e3
+        assert rp[0] == want
+        canvas.append({"start": list(s), "goal": list(g), "jump_points": len(want), "us_per_call_resident_grid": us,
+                       "us_per_call_jps1_method": us_m, "kernel_us": p.timing()["search_kernel_ms"] * 1e3,
+                       "c_port_us_one_core": us_c, "python_restatement_ms_one_core": ms_py})
+    maps = []
+    for nm in z.files:
+        rec = [r for r in recs if r["map"] == nm and "canvas" not in r][0]
+        W, H = rec["shape"]
+        grid = np.unpackbits(z[nm])[:W * H].reshape(W, H).astype(np.uint8)
+        free = np.argwhere(grid == 0)
+        s, g = tuple(int(v) for v in free[0]), tuple(int(v) for v in free[-1])
+        p.set_grid_occ(grid)
+        us, path = timed(lambda: p.plan(s, g, 2), 5)
+        us_c, rc = timed(lambda: oracle.plan(grid, s, g, 2, literal=False), 5)
+        assert (path if path else 0) == rc[0], "c1: %s differs from the oracle" % nm
+        maps.append((us, us_c, W * H))
+    mu = np.array([m[0] for m in maps])
+    mc = np.array([m[1] for m in maps])
+    us_mean = float(np.mean([c["us_per_call_resident_grid"] for c in canvas]))
+    return {"value": 1e6 / us_mean, "unit": "plans/s (one query per call)", "us_per_call": us_mean,
+            "describe": "BASELINE config 1: the 147x112 reference map in a 256x256 canvas, the three SURVEY 8(c) queries, one query per call "
+                        "(mean of %d calls each); then the 35 reference maps, first-free -> last-free" % reps,
+            "canvas_queries": canvas,
+            "maps35_us_per_call": {"mean": float(mu.mean()), "median": float(np.median(mu)), "max": float(mu.max()), "min": float(mu.min())},
+            "maps35_c_port_us_one_core": {"mean": float(mc.mean()), "median": float(np.median(mc)), "max": float(mc.max())},
+            "maps35_cells": {"min": int(min(m[2] for m in maps)), "max": int(max(m[2] for m in maps))},
+            "checked": "every path against jps1.py's (canvas) / the C oracle (maps)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5local4k", "c5pipe"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5local4k", "c5pipe"])
     ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N) (the default when "
                     "bench.py is not started by torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -301,6 +372,14 @@ def main():
                 cx.dist.barrier()
     cx.sync = sync
 
+    if a.workload == "c1":  # single calls: a latency, reported on its own line
+        r = measure_c1(cx)
+        print(json.dumps({"metric": "start->goal plans/sec, one query per call, 256x256 canvas of a reference map", "value": r["value"], "unit": "plans/s",
+                          "n_gpus": 1, "steps": 20, "warmup": 1, "ms_per_step": r["us_per_call"] / 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "the reference's maps/*.png (tests/golden/maps_png.npz)",
+                          "config": {"workload": "c1: " + r["describe"], "detail": r}}), flush=True)
+        cx.planner.close()
+        return
     m = measure(cx, a.workload, a.steps, a.warmup, a.frames_in_flight)
 
     # ---- the other BASELINE workloads, behind the headline's timed region (default invocation only)
@@ -317,6 +396,7 @@ def main():
             if r:
                 also["c4shard"] = brief(r)
             if cx.world == 1:
+                also["c1"] = measure_c1(cx)
                 r = measure(cx, "c3", 1, 0)  # BASELINE config 3: one timed step (100 000 queries on 4096^2, ~ 10 s), no warm-up
                 if r:
                     also["c3"] = brief(r, ("retried",))

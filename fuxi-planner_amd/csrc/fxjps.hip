@@ -112,6 +112,7 @@ struct DevCtx {
     int solo_timeouts = 0;              // waits for that counter that ran into their 5 ms bound (3: no more head launches here)
     size_t cells_bound = 0;             // bytes the batch in progress may still allocate for its packed paths
     bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
+    bool lds_attr_coop[2] = {};         // ... and k_search_coop's
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_solo0 = nullptr, ev_solo1 = nullptr;
     hipEvent_t ev_hd0 = nullptr, ev_hd1 = nullptr, ev_bt0 = nullptr, ev_bt1 = nullptr;  // around the head launch / the batch's launch alone
     bool had_solo = false;              // the last regular-pool launch was two launches
@@ -162,6 +163,7 @@ struct DevCtx {
     hipEvent_t ev_upd = nullptr;
     bool upd_pending = false;
     HBuf<int32_t> h_len, h_cells;
+    HBuf<uint32_t> h_path1;       // single calls: the search kernel writes the packed path of its one query here
     HBuf<double> h_cost;
     HBuf<long long> h_offsets;
     HBuf<unsigned long long> h_counters;
@@ -184,6 +186,7 @@ struct fxjps {
     int mem_div = 1;          // handles sharing each device (fxjps_set_memory_share): the scratch budgets are divided by it
     fxjps_timing_t timing{};
     int64_t last_nq = 0;
+    bool last_on_host = false;  // the last batch was a single call: its CSR is in the pinned host buffers only
     // persistent query set of the streaming-replan entry points (fxjps_set_queries / fxjps_replan_frame)
     std::vector<int32_t> q_starts, q_goals;
     int q_hchoice = 0, q_max_len = 0;
@@ -512,9 +515,18 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     return FXJPS_OK;
 }
 
+void fill_search_args(const DevCtx& d, int pool, SearchArgs& A, const uint32_t* d_order, uint32_t nrun, int max_len, bool track);
+int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const ScratchCfg& c, const uint32_t* d_order, uint32_t nrun, int hchoice, bool track);
+
 int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32_t nrun, int hchoice, int max_len, bool track = false) {
     const ScratchCfg& c = d.cfg[pool];
     SearchArgs A;
+    fill_search_args(d, pool, A, d_order, nrun, max_len, track);
+    return launch_search_args(h, d, pool, A, c, d_order, nrun, hchoice, track);
+}
+
+void fill_search_args(const DevCtx& d, int pool, SearchArgs& A, const uint32_t* d_order, uint32_t nrun, int max_len, bool track) {
+    const ScratchCfg& c = d.cfg[pool];
     A.G = grid_of(d);
     A.starts = d.d_starts.p;
     A.goals = d.d_goals.p;
@@ -545,6 +557,9 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     A.next = d.d_next.p;
     A.wave_gen = d.wave_gen[pool].p;
     A.max_pops = 64ull * (unsigned long long)d.W * d.H + 4096ull;
+}
+
+int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const ScratchCfg& c, const uint32_t* d_order, uint32_t nrun, int hchoice, bool track) {
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
     waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
     waves = std::min<uint32_t>(waves, c.nwaves);
@@ -571,11 +586,25 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
     nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
     if (nsolo != 0u) waves = std::min<uint32_t>(waves, (c.nwaves - nsolo) & ~((uint32_t)fx::WPB - 1u));
     if (pool != 0 || nsolo != 0u || (uint64_t)nrun > (uint64_t)d.n_cu * live_main || d.share * h->mem_div > 1) live_main = 0u;
+    // One query per BLOCK (k_search_coop: a searching wavefront and a stager that keeps the LDS tier of its open list in
+    // shape, two SIMDs of a CU): for what a handful of long queries decide -- the head launch above, and batches small
+    // enough for every query to get a block at once (the frames of config 5, single calls).  Tables indexed by the cell
+    // only (grids of up to 2^20 slots), no read-set recording.  FXJPS_COOP=0 / FXJPS_COOP_MAX=n: measurement and test aids.
+    uint32_t coop_max = 1024u;
+    if (const char* e = getenv("FXJPS_COOP_MAX")) coop_max = (uint32_t)std::max(0, atoi(e));
+    // (measured in round 4 and left OFF: the stager answers within ~230 cycles of being asked and takes two refills in three
+    // off the searching wavefront -- but a refill turned out to cost that wavefront ~2 300 cycles, not the 6 000 the
+    // instrumented build had shown, and taking a block plus re-inserting the late list costs about as much: query 9206
+    // alone 69.0 -> 70.7 ms, config 2 130.7 k -> 123 k plans/s with the head launch on such blocks, a config-5 frame
+    // 64.5 -> 64.0 ms.  FXJPS_COOP=1 switches it on; tests/test_gpu_fullsize.py::test_cooperative_blocks keeps it exact.)
+    const bool coop_ok = pool == 0 && !track && c.direct_ly > 0 && getenv("FXJPS_COOP") && atoi(getenv("FXJPS_COOP")) != 0;
+    const bool coop_all = coop_ok && nsolo == 0u && live_main == 0u && nrun <= coop_max && nrun <= c.nwaves;
+    if (coop_all) waves = std::min<uint32_t>(c.nwaves, nrun);  // blocks, one scratch slot each
     if (pool == 0) d.waves_used = waves;
     HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, 2 * sizeof(unsigned int), d.stream));
     const dim3 block(fx::WAVE * fx::WPB);
-    DBG("launch k_search pool=%d waves=%u nrun=%u buckets=%u far_cap=%u solo=%u x %u spread=%u", pool, waves, nrun, c.nbuckets, c.far_cap, nsolo,
-        live_solo, live_main);
+    DBG("launch k_search pool=%d waves=%u nrun=%u buckets=%u far_cap=%u solo=%u x %u spread=%u coop=%d", pool, waves, nrun, c.nbuckets, c.far_cap, nsolo,
+        live_solo, live_main, coop_all ? 2 : (coop_ok ? 1 : 0));
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
     // instantiations: heuristic x read-set recording (fxjps_replan_frame) x table indexed by the cell
     {
@@ -598,6 +627,17 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
                 }
             }
         }
+        const KFn cfn = hchoice == 1 ? fx::k_search_coop<1> : fx::k_search_coop<2>;
+        static const size_t cpad = 100u << 10;  // the head launch's blocks: 21 KB of their own + this: no second block, and none of the batch's (66 KB), fits the CU
+        bool coop_head = coop_ok && nsolo != 0u && live_solo == 1u;
+        if (coop_head && !d.lds_attr_coop[hchoice == 1 ? 0 : 1]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(cfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cpad) == hipSuccess) {
+                d.lds_attr_coop[hchoice == 1 ? 0 : 1] = true;
+            } else {
+                (void)hipGetLastError();
+                coop_head = false;
+            }
+        }
         if (nsolo != 0u) {
             SearchArgs B = A;
             B.nrun = nsolo;
@@ -610,6 +650,9 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
             HIPCHK(h, hipEventRecord(d.ev_solo0, d.stream));
             HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_solo0, 0));
             HIPCHK(h, hipEventRecord(d.ev_hd0, d.stream_solo));
+            if (coop_head)
+                hipLaunchKernelGGL(cfn, dim3(nsolo), dim3(fx::WAVE * 2), cpad, d.stream_solo, B);
+            else
             hipLaunchKernelGGL(fn, dim3(nsolo / live_solo), block, pad, d.stream_solo, B);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(d.ev_hd1, d.stream_solo));
@@ -630,7 +673,9 @@ int launch_search(fxjps* h, DevCtx& d, int pool, const uint32_t* d_order, uint32
             }
         }
         if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, d.stream));
-        if (live_main != 0u) {
+        if (coop_all) {
+            hipLaunchKernelGGL(cfn, dim3(waves), dim3(fx::WAVE * 2), 0, d.stream, A);
+        } else if (live_main != 0u) {
             A.solo = live_main;
             hipLaunchKernelGGL(fn, dim3(waves / live_main), block, pad, d.stream, A);
         } else {
@@ -804,6 +849,85 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     return FXJPS_OK;
 }
 
+// One query per call -- the node's real use of the drop-in (global_planner_st.py:285: jps1.method once per tick, on maps
+// of ~150 x 110 cells).  The batch machinery around the search (uploads of the query arrays and of the longest-first
+// order, the work counter, the length scan and the CSR gather with their three host waits) costs more than such a search:
+// here the start and the goal travel in the kernel arguments, ONE wavefront runs the query, and the kernel writes the
+// path, its length and its cost straight into the handle's pinned host buffers -- one launch, one host wait.  Results
+// land where plan_core's other path leaves them (h_len / h_cost / h_offsets / h_cells), so the callers above see no
+// difference.  Returns 1 when the query has to go through the batch path after all (it outgrew the regular scratch).
+int plan_single(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, int hchoice, int max_len) {
+    HIPCHK(h, hipSetDevice(d.dev));
+    d.q0 = 0;
+    d.nq = 1;
+    d.mode = 0;
+    d.kernel_ms = 0;
+    d.launches = 0;
+    d.retried = 0;
+    d.nrun = 1;
+    d.waves_used = 1;
+    d.waves_short = false;
+    d.had_solo = false;
+    d.head_ms = d.batch_ms = 0;
+    HIPCHK(h, d.h_len.ensure(1));
+    HIPCHK(h, d.h_cost.ensure(1));
+    HIPCHK(h, d.h_offsets.ensure(2));
+    HIPCHK(h, d.h_counters.ensure(64));
+    HIPCHK(h, d.d_counters.ensure(64));
+    HIPCHK(h, d.h_path1.ensure((size_t)max_len));
+    HIPCHK(h, d.h_cells.ensure((size_t)max_len * 2));
+    d.cells_bound = 0;
+    int rc = ensure_pool(h, d, 0, (uint32_t)fx::WPB);
+    if (rc) return rc;
+    const ScratchCfg& c = d.cfg[0];
+    SearchArgs A;
+    fill_search_args(d, 0, A, nullptr, 1u, max_len, false);
+    A.starts = nullptr;
+    A.goals = nullptr;
+    A.next = nullptr;
+    A.qstat = nullptr;
+    A.single = 1u;
+    A.solo = 1u;
+    A.imm[0] = starts[0];
+    A.imm[1] = starts[1];
+    A.imm[2] = goals[0];
+    A.imm[3] = goals[1];
+    void *dp_path = nullptr, *dp_len = nullptr, *dp_cost = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer(&dp_path, d.h_path1.p, 0));
+    HIPCHK(h, hipHostGetDevicePointer(&dp_len, d.h_len.p, 0));
+    HIPCHK(h, hipHostGetDevicePointer(&dp_cost, d.h_cost.p, 0));
+    A.out_path = (uint32_t*)dp_path;
+    A.out_len = (int32_t*)dp_len;
+    A.out_cost = (double*)dp_cost;
+    d.h_len.p[0] = fx::QI_WATCHDOG;  // (overwritten by the kernel)
+    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 64 * sizeof(unsigned long long), d.stream));
+    HIPCHK(h, hipEventRecord(d.ev0, d.stream));
+    {
+        using KFn = void (*)(SearchArgs);
+        static const KFn kfn[2][2] = {{fx::k_search<1, false, false>, fx::k_search<1, false, true>},
+                                      {fx::k_search<2, false, false>, fx::k_search<2, false, true>}};
+        hipLaunchKernelGGL(kfn[hchoice == 1 ? 0 : 1][c.direct_ly > 0 ? 1 : 0], dim3(1), dim3(fx::WAVE * fx::WPB), 0, d.stream, A);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipEventRecord(d.ev1, d.stream));
+    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
+    d.kernel_ms = ms;
+    d.launches = 1;
+    const int32_t n = d.h_len.p[0];
+    if (n <= fx::QI_TABLE_FULL) return 1;  // outgrew the regular scratch (or the watchdog): the batch path has the large pool
+    d.h_offsets.p[0] = 0;
+    d.h_offsets.p[1] = n > 0 ? n : 0;
+    for (int32_t i = 0; i < n; i++) {
+        const uint32_t v = d.h_path1.p[i];
+        d.h_cells.p[2 * i] = (int32_t)(v >> 16);
+        d.h_cells.p[2 * i + 1] = (int32_t)(v & 0xFFFFu);
+    }
+    return FXJPS_OK;
+}
+
 int update_cells_async(fxjps* h, const int32_t* xy, const uint8_t* val, int64_t n, bool derive);  // (below, with the streaming entry points)
 void drain_all(fxjps* h);
 
@@ -830,8 +954,20 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
     }
     h->q_results_valid = false;  // (fxjps_replan_frame sets it again once its frame is complete)
     int rc = FXJPS_OK;
-    for (int r = 0; r < nd && !rc; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
-    for (int r = 0; r < nd && !rc; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
+    h->last_on_host = false;
+    static const bool single_ok = !(getenv("FXJPS_SINGLE") && atoi(getenv("FXJPS_SINGLE")) == 0) && !getenv("FXJPS_QSTAT");  // (0: test / measurement aid)
+    bool done = false;
+    if (nq == 1 && nd == 1 && mode == 0 && single_ok) {
+        rc = plan_single(h, h->devs[0], starts, goals, hchoice, max_len);
+        if (rc == 1) {
+            rc = FXJPS_OK;  // (rare: on to the batch path)
+        } else {
+            done = true;
+            h->last_on_host = rc == FXJPS_OK;
+        }
+    }
+    for (int r = 0; r < nd && !rc && !done; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
+    for (int r = 0; r < nd && !rc && !done; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
     if (rc) {
         drain_all(h);  // before the error leaves the library
         for (auto& d : h->devs) d.nq = 0;  // (no shard holds a result)
@@ -1106,6 +1242,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_counters.release();
         d.h_upd_xy.release();
         d.h_upd_val.release();
+        d.h_path1.release();
         if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
         if (d.solo_started) (void)hipHostFree(d.solo_started);
         if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
@@ -1714,6 +1851,11 @@ int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, co
     if (nq < 0 || !origin || (nq > 0 && (!pos || !goal || !out_wp))) return fail(h, FXJPS_E_ARG, "bad waypoint arguments");
     if ((cells_xy != nullptr) != (offsets != nullptr)) return fail(h, FXJPS_E_ARG, "offsets and cells_xy go together");
     if (!cells_xy && nq != h->last_nq) return fail(h, FXJPS_E_ARG, "the last batch had %lld queries, not %lld", (long long)h->last_nq, (long long)nq);
+    if (!cells_xy && h->last_on_host) {  // (a single call leaves its path in the pinned host buffers: handed over like a caller's CSR)
+        static_assert(sizeof(long long) == sizeof(int64_t), "offsets are handed over as they are");
+        offsets = reinterpret_cast<const int64_t*>(h->devs[0].h_offsets.p);
+        cells_xy = h->devs[0].h_cells.p;
+    }
     if (h->maps_stale) {  // (the grid is what the line test reads; deferred updates are queued on the same streams anyway)
         int rc = update_cells_async(h, nullptr, nullptr, 0, true);
         if (rc) return rc;

@@ -359,6 +359,80 @@ def test_longest_queries_on_cus_of_their_own(planner, oracle):
             assert_same(planner.plan_batch(s[:200], g[:200], 2, 1024), planner.plan_batch(s[:200], g[:200], 2, 1024))
 
 
+def test_cooperative_blocks(planner, oracle):
+    """One query per BLOCK (k_search_coop, FXJPS_COOP=1: a searching wavefront and a stager that prepares the next sorted
+    block of its register tier from the LDS tier of the open list): small batches run every query on such a block, batches
+    of 4 096 and more their head launch.  Same bytes as the one-wavefront search, both heuristics; the oracle checks."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(1024, 1024, 1, 0.20)
+    s, g = synth.synth_queries(occ, 1, 6000)
+    planner.set_grid_occ(occ)
+    for h in (2, 1):
+        small = planner.plan_batch(s[:700], g[:700], h, 1024)
+        big = planner.plan_batch(s, g, h, 1024)
+        want = oracle_csr(oracle, occ, s[:700], g[:700], h, 1024)
+        assert_same(small, want)
+        with with_env(FXJPS_COOP=1):
+            assert_same(planner.plan_batch(s[:700], g[:700], h, 1024), small)
+            assert_same(planner.plan_batch(s, g, h, 1024), big)
+            assert_same(planner.plan_batch(s[:3], g[:3], h, 1024), planner.plan_batch(s[:3], g[:3], h, 1024))
+    # other maps: open areas (long refills of the far tier), a maze (deep open lists), tiny grids
+    for W, H, p_occ, seed in ((300, 260, 0.05, 3), (257, 511, 0.33, 4), (40, 33, 0.2, 5)):
+        occ = synth.synth_grid(W, H, seed, p_occ)
+        s, g = synth.synth_queries(occ, seed, 400)
+        planner.set_grid_occ(occ)
+        want = oracle_csr(oracle, occ, s, g, 2, 4096)
+        with with_env(FXJPS_COOP=1):
+            assert_same(planner.plan_batch(s, g, 2, 4096), want)
+
+
+def test_single_call_path(planner, oracle):
+    """nq == 1 takes the one-launch path (start and goal in the kernel arguments, results written straight into the
+    handle's pinned host buffers): same bytes as the batch path (FXJPS_SINGLE is read once per process, so the batch path
+    is asked for with two copies of the query), no path / start == goal / start outside / path too long, a query that
+    outgrows the regular scratch and goes on to the batch path's large pool, and the batch waypoint entry point behind it."""
+    from fuxi_planner_amd import synth
+    occ = synth.synth_grid(300, 280, 9, 0.22)
+    s, g = synth.synth_queries(occ, 9, 60)
+    planner.set_grid_occ(occ)
+    for h in (2, 1):
+        for q in range(60):
+            one = planner.plan_batch(s[q:q + 1], g[q:q + 1], h, 1024)
+            two = planner.plan_batch(np.repeat(s[q:q + 1], 2, axis=0), np.repeat(g[q:q + 1], 2, axis=0), h, 1024)
+            assert one[3][0] == two[3][0] and one[2][:1].tobytes() == two[2][:1].tobytes()
+            assert np.array_equal(one[1], two[1][:two[0][1]])
+        want = oracle_csr(oracle, occ, s, g, h, 1024)
+        for q in range(0, 60, 7):
+            one = planner.plan_batch(s[q:q + 1], g[q:q + 1], h, 1024)
+            assert np.array_equal(one[1], want[1][want[0][q]:want[0][q + 1]]) and one[2][0] == want[2][q]
+    assert planner.timing()["search_launches"] == 1
+    # special outcomes
+    blocked = np.argwhere(occ == 1)[0]
+    for st, gl, code in (((5, 5), (5, 5), 1), ((-1, 3), (5, 5), -2), ((400, 3), (5, 5), -2)):
+        r = planner.plan_batch([st], [gl], 2, 64)
+        assert r[3][0] == code, (st, gl, r[3])
+    r = planner.plan_batch([tuple(s[0])], [tuple(blocked)], 2, 64)
+    assert r[3][0] == 0 and len(r[1]) == 0
+    r = planner.plan_batch(s[:1], g[:1], 2, 2)  # a path longer than its slot
+    assert r[3][0] == -1
+    # a table of 2^8 entries: the single call hands the query on to the batch path and its large pool
+    want = oracle_csr(oracle, occ, s, g, 2, 1024)
+    with with_env(FXJPS_TABLE_LOG2=8):
+        planner.set_grid_occ(occ)
+        one = planner.plan_batch(s[3:4], g[3:4], 2, 1024)
+        assert planner.timing()["retried"] == 1
+        assert np.array_equal(one[1], want[1][want[0][3]:want[0][4]])
+    planner.set_grid_occ(occ)
+    # the resident form of the batch waypoint selection behind a single call
+    one = planner.plan_batch(s[5:6], g[5:6], 2, 1024)
+    pos = np.array([[0.3, 0.2, 0.0]]); goal = np.array([[9.0, 8.0, 0.0]])
+    from fuxi_planner_amd import waypoints
+    wa = waypoints.select_ccst_batch(planner, 1, 0.1, (0.0, 0.0), pos, goal)
+    wb = waypoints.select_ccst_batch(planner, 1, 0.1, (0.0, 0.0), pos, goal, paths=(one[0], one[1]))
+    for a_, b_ in zip(wa, wb):
+        assert np.array_equal(np.asarray(a_), np.asarray(b_))
+
+
 def test_head_launch_on_other_maps(planner, oracle):
     """The head launch and the longest-first key on maps that are not config 2's: rooms with doors, blobs, a maze, an
     empty map, a dense one -- batches of 4 096 .. 5 000 queries (the head launch runs), both heuristics, every query
