@@ -109,7 +109,9 @@ struct DevCtx {
     hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
     uint32_t* solo_started = nullptr;   // pinned host word: blocks of such launches that have started (only ever counts up)
     uint32_t solo_target = 0;           // ... and how many have been launched
-    int solo_timeouts = 0;              // waits for that counter that ran into their 5 ms bound (3: no more head launches here)
+    int solo_timeouts = 0;              // waits for that counter that ran into their 5 ms bound, since the handle was created
+    int solo_timeouts_run = 0;          // ... in a row (3: no more head launches on this device; a cold first launch of a
+                                        // kernel -- its code object is loaded then -- is a lone timeout and means nothing)
     size_t cells_bound = 0;             // bytes the batch in progress may still allocate for its packed paths
     bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
     bool lds_attr_coop[2] = {};         // ... and k_search_coop's
@@ -580,7 +582,7 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
     if (const char* e = getenv("FXJPS_SPREAD")) live_main = (uint32_t)std::max(0, atoi(e));
     if (live_solo != 1u && live_solo != 2u && live_solo != 4u) live_solo = 4u;
     if (live_main != 0u && live_main != 1u && live_main != 2u && live_main != 4u) live_main = 4u;
-    if (pool != 0 || track || d_order == nullptr || d.solo_started == nullptr || d.solo_timeouts >= 3 || nrun < 4096u || nrun < 64u * nsolo ||
+    if (pool != 0 || track || d_order == nullptr || d.solo_started == nullptr || d.solo_timeouts_run >= 3 || nrun < 4096u || nrun < 64u * nsolo ||
         waves <= 2u * nsolo + (uint32_t)fx::WPB)
         nsolo = 0;
     nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
@@ -663,14 +665,17 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
             // (rocprofv3 --pmc).  After 5 ms the batch goes ahead regardless -- placement is speed, never correctness.
             d.solo_target += nsolo / live_solo;
             const auto t0 = std::chrono::steady_clock::now();
+            bool late = false;
             while ((int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
-                    // (the counter never arrived -- no PCIe atomics, a tool that serialises kernels: after three such
-                    // waits this device runs its batches as one launch; fxjps_timing_t::solo_timeouts says so)
-                    d.solo_timeouts++;
+                    // (the counter did not arrive in time -- no PCIe atomics, a tool that serialises kernels: after three
+                    // such waits in a row this device runs its batches as one launch; fxjps_timing_t::solo_timeouts counts them)
+                    late = true;
                     break;
                 }
             }
+            d.solo_timeouts += late ? 1 : 0;
+            d.solo_timeouts_run = late ? d.solo_timeouts_run + 1 : 0;
         }
         if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, d.stream));
         if (coop_all) {

@@ -207,7 +207,8 @@ typedef struct fxjps_timing {
     double head_launch_ms;   /* search_launches == 2: HIP-event time of the launch of the longest queries alone ... */
     double batch_launch_ms;  /* ... and of the launch of the rest of the batch beside it (0 when the batch was one launch) */
     int64_t solo_timeouts;   /* waits for the head launch's blocks to report from their CUs that ran into their 5 ms bound,
-                                since the handle was created (3 on a device: it runs its batches as one launch from then on) */
+                                since the handle was created (3 in a row on a device: it runs its batches as one launch from
+                                then on; a lone one is the cold first launch of a kernel) */
 } fxjps_timing_t;
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
 
