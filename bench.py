@@ -176,7 +176,11 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     if pipe is not None:
         k_ms = None
     k_all = [k_ms]
-    if cx.world > 1:
+    if cx.world > 1 and cx.rdv is not None:  # (no torch: maximum and per-rank kernel times over the rendezvous socket)
+        parts = cx.rdv.bcast(cx.rdv.gather([elapsed, k_ms]))
+        elapsed = max(float(x[0]) for x in parts)
+        k_all = [float(x[1]) for x in parts]
+    elif cx.world > 1:
         t = cx.torch.tensor([elapsed, k_ms], dtype=cx.torch.float64, device=cx.tdev)
         allk = [cx.torch.zeros_like(t) for _ in range(cx.world)]
         cx.dist.all_gather(allk, t)
@@ -339,13 +343,18 @@ def main():
     with open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")) as f:
         cx.WL = json.load(f)
 
-    cx.torch = cx.dist = cx.sp = None
-    # Bring-up aid for 1-GPU boxes (never set by the driver): FXJPS_BENCH_BACKEND=gloo runs every rank on
-    # device 0 with a host-side broadcast, to exercise the multi-rank code path without a second GPU;
-    # FXJPS_BENCH_ONE_DEVICE=1 gives the in-library handle N contexts on device 0 (everything but the collective).
-    backend = os.environ.get("FXJPS_BENCH_BACKEND", "nccl")
-    cx.dev_index = 0 if backend == "gloo" else local_rank
-    if cx.world > 1:
+    cx.torch = cx.dist = cx.sp = cx.rdv = None
+    # One process per GPU (WORLD_SIZE > 1, e.g. under torch.distributed.run): by default NO torch in the process -- the
+    # ranks meet over a TCP socket at MASTER_ADDR : MASTER_PORT + 1 (fuxi_planner_amd.ranks), rank 0 hands out the RCCL
+    # id, the library broadcasts the grid (fxjps_create_rank / fxjps_set_grid_rank).  FXJPS_BENCH_BACKEND=nccl | gloo keeps
+    # the round-3 path through torch.distributed (nccl: RCCL through torch; gloo: every rank on device 0, host broadcast).
+    # Bring-up aids for 1-GPU boxes (never set by the driver): FXJPS_BENCH_ONE_DEVICE=1 puts every rank (or every context
+    # of the in-library handle) on device 0 -- everything but the collective, which RCCL refuses between ranks that share
+    # a device: the grid bytes then travel over the rendezvous socket.
+    backend = os.environ.get("FXJPS_BENCH_BACKEND", "ranks")
+    one_dev = bool(os.environ.get("FXJPS_BENCH_ONE_DEVICE"))
+    cx.dev_index = 0 if (backend == "gloo" or one_dev) else local_rank
+    if cx.world > 1 and backend != "ranks":
         import torch
         import torch.distributed as dist
         cx.torch, cx.dist = torch, dist
@@ -353,18 +362,28 @@ def main():
         dist.init_process_group(backend, rank=cx.rank, world_size=cx.world)  # "nccl" is RCCL on ROCm
         cx.tdev = "cpu" if backend == "gloo" else "cuda:%d" % cx.dev_index
 
-    if cx.inlib:
-        devs = [0] * a.gpus if os.environ.get("FXJPS_BENCH_ONE_DEVICE") else list(range(a.gpus))
+    if cx.world > 1 and backend == "ranks":
+        from fuxi_planner_amd.ranks import RankPlanner, Rendezvous
+        cx.rdv = Rendezvous.from_env()
+        cx.sp = RankPlanner(cx.rdv, device=cx.dev_index, host_broadcast=one_dev)
+        cx.planner = cx.sp.engine
+        if one_dev:
+            cx.planner.set_memory_share(cx.world)  # (the rehearsal's ranks share device 0: a host that does that says so)
     else:
-        devs = [cx.dev_index]
-    cx.planner = fx.Planner(devs)
-    if cx.world > 1 and backend == "gloo":
-        cx.planner.set_memory_share(cx.world)  # (the rehearsal's ranks share device 0: a host that does that says so)
-    if cx.world > 1:
-        cx.sp = ShardedPlanner(cx.planner, device=cx.tdev)
+        if cx.inlib:
+            devs = [0] * a.gpus if one_dev else list(range(a.gpus))
+        else:
+            devs = [cx.dev_index]
+        cx.planner = fx.Planner(devs)
+        if cx.world > 1 and backend == "gloo":
+            cx.planner.set_memory_share(cx.world)
+        if cx.world > 1:
+            cx.sp = ShardedPlanner(cx.planner, device=cx.tdev)
 
     def sync():
-        if cx.world > 1:
+        if cx.rdv is not None:
+            cx.rdv.barrier()  # (the planner's calls are blocking: results are in host memory when they return)
+        elif cx.world > 1:
             cx.torch.cuda.synchronize()
             if backend == "nccl":
                 cx.dist.barrier(device_ids=[cx.dev_index])
@@ -408,7 +427,11 @@ def main():
 
     if cx.rank == 0:
         ci = cx.planner.comm_info()
-        if cx.world > 1:
+        if cx.world > 1 and cx.rdv is not None:
+            rccl_ranks = ci["rccl_ranks"]
+            collective = ("ncclBroadcast of the grid inside the library (fxjps_set_grid_rank), ncclCommCount = %d; rendezvous over TCP, no torch in the process" % rccl_ranks) \
+                if rccl_ranks else "none: the ranks share one device (rehearsal), the grid bytes travel over the rendezvous socket"
+        elif cx.world > 1:
             rccl_ranks = cx.world if backend == "nccl" else 0
             collective = "torch.distributed %s broadcast of the grid, %d ranks" % ("nccl (RCCL)" if backend == "nccl" else backend, cx.world)
         else:
@@ -442,7 +465,8 @@ def main():
             "config": {"workload": "%s: %s" % (a.workload, m["describe"]),
                        "queries_per_step": m["total_q"], "queries_on_rank0": m["n_local"], "grid": [m["W"], m["H"]], "hchoice": m["hchoice"],
                        "reachable_rank0": int((m["status"] > 0).sum()), "retried_on_large_scratch": m["retried"],
-                       "parallelism": ("one process, fxjps_create(n_dev=%d)" % a.gpus) if cx.inlib else "queries sharded x%d, one process per GPU" % a.gpus,
+                       "parallelism": ("one process, fxjps_create(n_dev=%d)" % a.gpus) if cx.inlib else "queries sharded x%d, one process per GPU%s" % (a.gpus, ", torch-free ranks" if cx.rdv is not None else ""),
+                       "torch_imported": "torch" in sys.modules,
                        "rccl_ranks": rccl_ranks, "collective": collective, "contexts": ci["contexts"] if cx.world == 1 else cx.world,
                        "kernel_ms_per_device": m["kernel_ms_per_device"], "resident_wavefronts": m["waves"], "wavefronts_cut_by_memory": m["waves_short"]},
             "roofline": {"bound": "hbm", "achieved": m["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -523,7 +547,10 @@ def main():
                                                             "%d of the host's %d hardware threads, %.1f s wall, %.1f s summed over the processes"
                                                             % (npy, nproc, os.cpu_count() or 1, wall, cpu_s)}
         print(json.dumps(out), flush=True)
-    if cx.world > 1:
+    if cx.rdv is not None:
+        cx.rdv.barrier()
+        cx.rdv.close()
+    elif cx.world > 1:
         cx.dist.destroy_process_group()
     if cx.planner is not None:
         cx.planner.close()

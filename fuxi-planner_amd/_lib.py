@@ -13,7 +13,7 @@ Q_NOPATH, Q_PATH_TOO_LONG, Q_BAD_START, Q_CAPACITY = 0, -1, -2, -3
 BACKEND_HIP = 1
 
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
-SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_destroy", "fxjps_last_error",
+SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_rank_unique_id", "fxjps_create_rank", "fxjps_set_grid_rank", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
            "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask", "fxjps_debug_read_maps", "fxjps_debug_counters", "fxjps_debug_qstat",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst", "fxjps_waypoint_ccst_batch", "fxjps_waypoint_st_batch")
@@ -109,6 +109,12 @@ def load():
     L.fxjps_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.fxjps_last_timing_device.restype = C.c_int
     L.fxjps_last_timing_device.argtypes = [vp, C.c_int32, p_i32, p_i64, p_f64, p_i64]
+    L.fxjps_rank_unique_id.restype = C.c_int
+    L.fxjps_rank_unique_id.argtypes = [vp]
+    L.fxjps_create_rank.restype = C.c_int
+    L.fxjps_create_rank.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.fxjps_set_grid_rank.restype = C.c_int
+    L.fxjps_set_grid_rank.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32]
     L.fxjps_comm_info.restype = C.c_int
     L.fxjps_comm_info.argtypes = [vp, p_i32, p_i32, p_i32]
     L.fxjps_set_memory_share.restype = C.c_int

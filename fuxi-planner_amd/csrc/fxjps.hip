@@ -200,6 +200,9 @@ struct fxjps {
     // deployment does not need librccl at load time
     void* rccl = nullptr;
     std::vector<void*> comms;
+    // one process per GPU without torch (fxjps_create_rank): this handle is rank `rank` of `world`, its one communicator
+    // (comms[0]) was made with ncclCommInitRank from the id rank 0 handed out
+    int rank = -1, world = 0;
 };
 
 namespace {
@@ -1020,8 +1023,33 @@ typedef int (*nccl_bcast_t)(const void*, void*, size_t, int, int, void*, hipStre
 typedef int (*nccl_group_t)(void);
 typedef int (*nccl_destroy_t)(void*);
 
+typedef struct {
+    char b[128];
+} nccl_uid_t;  // ncclUniqueId: NCCL_UNIQUE_ID_BYTES = 128
+typedef int (*nccl_get_uid_t)(nccl_uid_t*);
+typedef int (*nccl_init_rank_t)(void**, int, nccl_uid_t, int);
+
+void* load_rccl(fxjps* h) {
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) fail(h, FXJPS_E_COMM, "cannot load librccl.so: %s", dlerror());
+    return lib;
+}
+
 int broadcast_grid(fxjps* h, int W, int H) {
     const int nd = (int)h->devs.size();
+    if (h->world > 0) {
+        // one process per GPU: this rank's part of the one collective of the path -- ncclBroadcast of the W*H occupancy
+        // bytes from rank 0 over xGMI, on this rank's stream (every rank calls fxjps_set_grid_rank with the same W, H)
+        if (h->world == 1 && !h->rccl) return FXJPS_OK;
+        auto bcast = (nccl_bcast_t)dlsym(h->rccl, "ncclBroadcast");
+        if (!bcast) return fail(h, FXJPS_E_COMM, "ncclBroadcast not found");
+        DevCtx& d = h->devs[0];
+        HIPCHK(h, hipSetDevice(d.dev));
+        if (bcast(d.occ.p, d.occ.p, (size_t)W * H, /*ncclUint8*/ 1, 0, h->comms[0], d.stream) != 0)
+            return fail(h, FXJPS_E_COMM, "ncclBroadcast failed on rank %d", h->rank);
+        return FXJPS_OK;
+    }
     // (FXJPS_FORCE_RCCL=1: test aid -- a one-device handle goes through the collective too: a communicator of one rank,
     // an in-place broadcast from itself.  Exercises the loading of librccl, the symbols, their signatures and the
     // communicator's life cycle on a one-GPU box.)
@@ -1188,6 +1216,70 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
     }
     *out = h;
     return FXJPS_OK;
+}
+
+int fxjps_rank_unique_id(void* out_id128) {
+    if (!out_id128) return fail(nullptr, FXJPS_E_ARG, "out_id128 == NULL");
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(nullptr, FXJPS_E_COMM, "cannot load librccl.so: %s", dlerror());
+    auto get = (nccl_get_uid_t)dlsym(lib, "ncclGetUniqueId");
+    if (!get) return fail(nullptr, FXJPS_E_COMM, "ncclGetUniqueId not found");
+    nccl_uid_t id;
+    memset(&id, 0, sizeof(id));
+    if (get(&id) != 0) return fail(nullptr, FXJPS_E_COMM, "ncclGetUniqueId failed");
+    memcpy(out_id128, &id, sizeof(id));
+    return FXJPS_OK;  // (the library stays loaded: the handle made next uses it)
+}
+
+int fxjps_create_rank(int device, int rank, int world, const void* id128, fxjps_t** out) {
+    if (!out) return fail(nullptr, FXJPS_E_ARG, "out == NULL");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(nullptr, FXJPS_E_ARG, "rank %d of %d", rank, world);
+    const int ids[1] = {device};
+    fxjps_t* h = nullptr;
+    int rc = fxjps_create(FXJPS_BACKEND_HIP, ids, 1, &h);
+    if (rc) return rc;
+    h->rank = rank;
+    h->world = world;
+    if (world > 1 || (getenv("FXJPS_FORCE_RCCL") && atoi(getenv("FXJPS_FORCE_RCCL")) != 0 && id128)) {
+        h->rccl = load_rccl(h);
+        auto init = h->rccl ? (nccl_init_rank_t)dlsym(h->rccl, "ncclCommInitRank") : nullptr;
+        if (!init) {
+            g_create_error = h->rccl ? "ncclCommInitRank not found" : h->err;
+            fxjps_destroy(h);
+            return FXJPS_E_COMM;
+        }
+        nccl_uid_t id;
+        memcpy(&id, id128, sizeof(id));
+        h->comms.assign(1, nullptr);
+        (void)hipSetDevice(device);
+        if (init(&h->comms[0], world, id, rank) != 0) {
+            g_create_error = "ncclCommInitRank failed";
+            fxjps_destroy(h);
+            return FXJPS_E_COMM;
+        }
+    }
+    *out = h;
+    return FXJPS_OK;
+}
+
+int fxjps_set_grid_rank(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
+    if (!h) return FXJPS_E_ARG;
+    if (h->world < 1) return fail(h, FXJPS_E_ARG, "fxjps_set_grid_rank on a handle that fxjps_create_rank did not make");
+    if (W < 1 || H < 1 || W > 8190 || H > 8190 || (h->rank == 0 && !occ)) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side (rank 0 passes it)");
+    h->have_grid = false;
+    h->q_results_valid = false;
+    DevCtx& d0 = h->devs[0];
+    int rc = alloc_grid(h, d0, W, H);
+    if (rc) return rc;
+    d0.pool_clean[0] = d0.pool_clean[1] = false;
+    d0.cfg[0] = ScratchCfg();
+    d0.cfg[1] = ScratchCfg();
+    HIPCHK(h, hipSetDevice(d0.dev));
+    if (h->rank == 0) HIPCHK(h, hipMemcpyAsync(d0.occ.p, occ, (size_t)W * H, hipMemcpyHostToDevice, d0.stream));
+    HIPCHK(h, hipStreamSynchronize(d0.stream));
+    return finish_set_grid(h, W, H);  // the broadcast (root = rank 0), then every rank derives its maps itself
 }
 
 void fxjps_destroy(fxjps_t* h) {

@@ -39,6 +39,46 @@ class Planner(object):
         self.devices = list(devices)
         self.shape = None
 
+    @classmethod
+    def for_rank(cls, device, rank, world, unique_id=None):
+        """One process per GPU without torch: this process is `rank` of `world` and plans on `device`; `unique_id` is the
+        128-byte RCCL id rank 0 got from `Planner.rank_unique_id()` (None for world == 1).  Collective: every rank calls it."""
+        L = _lib.load()
+        if L.fxjps_device_count() <= 0:
+            raise FxjpsError(_lib.E_NODEV, "no HIP device visible: fuxi-planner_amd has no CPU fallback")
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128) if unique_id is not None else None
+        rc = L.fxjps_create_rank(int(device), int(rank), int(world), buf, C.byref(h))
+        if rc != 0:
+            raise FxjpsError(rc, (L.fxjps_last_error(None) or b"").decode())
+        self = cls.__new__(cls)
+        self._L = L
+        self._h = h
+        self.devices = [int(device)]
+        self.shape = None
+        self.rank, self.world = int(rank), int(world)
+        return self
+
+    @staticmethod
+    def rank_unique_id():
+        """The id of a new RCCL communicator (ncclGetUniqueId): rank 0 makes it and hands it to the other ranks."""
+        L = _lib.load()
+        buf = C.create_string_buffer(128)
+        rc = L.fxjps_rank_unique_id(buf)
+        if rc != 0:
+            raise FxjpsError(rc, (L.fxjps_last_error(None) or b"").decode())
+        return buf.raw
+
+    def set_grid_rank(self, occ, W, H):
+        """Collective over the ranks of `for_rank`: rank 0 passes the uint8 [W][H] occupancy, the others None; ONE
+        ncclBroadcast of the W*H bytes inside the library, then every rank builds its maps."""
+        if occ is not None:
+            occ = np.ascontiguousarray(occ, dtype=np.uint8)
+            if occ.shape != (W, H):
+                raise ValueError("grid shape %r is not (%d, %d)" % (occ.shape, W, H))
+        self._chk(self._L.fxjps_set_grid_rank(self._h, _lib.ptr(occ, C.c_uint8) if occ is not None else None, int(W), int(H)))
+        self.shape = (int(W), int(H))
+
     # -- lifetime
     def close(self):
         if getattr(self, "_h", None):

@@ -70,6 +70,18 @@ int fxjps_device_count(void);
  * FXJPS_BACKEND_HIP; there is no CPU backend. */
 int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out);
 
+/* One process per GPU without any framework in the process (north_star: "no PyTorch"; the reference shares nothing
+ * between calls, jps1.py:183-192, so the ranks need only the grid).  Rank 0 asks RCCL for a communicator id
+ * (ncclGetUniqueId: 128 bytes) and hands it to the other ranks by whatever channel the launcher has -- bench.py and
+ * fuxi_planner_amd.ranks use a TCP socket at MASTER_ADDR:MASTER_PORT+1; every rank then creates its handle on its own
+ * device with fxjps_create_rank (ncclCommInitRank: collective, all ranks call it), and every rank calls
+ * fxjps_set_grid_rank with the same W, H -- rank 0 with the occupancy bytes, the others with NULL: ONE ncclBroadcast of
+ * W*H bytes over xGMI, then each rank builds its maps itself and plans its own contiguous slice of the queries
+ * (fxjps_plan_batch* as on any handle).  world == 1 needs no id and makes no communicator. */
+int fxjps_rank_unique_id(void* out_id128);
+int fxjps_create_rank(int device, int rank, int world, const void* id128, fxjps_t** out);
+int fxjps_set_grid_rank(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H);
+
 void fxjps_destroy(fxjps_t* h);
 
 /* Last error text for this handle (h == NULL: last create error). */

@@ -804,6 +804,60 @@ def test_rccl_path_with_one_rank(tmp_path):
     assert "'rccl_ranks': 1" in r.stdout, r.stdout
 
 
+_RANK1 = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ["FXJPS_FORCE_RCCL"] = "1"
+import numpy as np
+import fuxi_planner_amd as fx
+from fuxi_planner_amd import synth
+from fuxi_planner_amd.ranks import Rendezvous, RankPlanner
+assert "torch" not in sys.modules
+occ = synth.synth_grid(300, 200, 3, 0.2)
+s, g = synth.synth_queries(occ, 3, 500)
+with fx.Planner([0]) as p:
+    p.set_grid_occ(occ)
+    ref = p.plan_batch(s, g, 2, 1024)
+# a communicator of ONE rank made the way the ranks of a sharded run make theirs: ncclGetUniqueId + ncclCommInitRank
+uid = fx.Planner.rank_unique_id()
+assert len(uid) == 128 and any(uid)
+pr = fx.Planner.for_rank(0, 0, 1, uid)
+pr.set_grid_rank(occ, 300, 200)                      # ncclBroadcast from itself, in place
+print(pr.comm_info())
+got = pr.plan_batch(s, g, 2, 1024)
+for a, b in zip(got, ref):
+    assert np.array_equal(a, b)
+assert np.array_equal(pr.get_grid(), occ)
+pr.set_grid_rank(occ[:100].copy(), 100, 200)         # the communicator is reused
+pr.close()
+# and the whole RankPlanner path with a world of one
+rp = RankPlanner(Rendezvous(0, 1), device=0)
+assert rp.set_grid(occ) == (300, 200)
+lo, hi, off, cells, cost, st = rp.plan_local(s, g, 2, 1024)
+m = rp.gather(off, cells, cost, st)
+assert (lo, hi) == (0, 500) and np.array_equal(m[1], ref[1]) and np.array_equal(m[3], ref[3])
+rp.close()
+assert "torch" not in sys.modules
+print("RANK1-OK")
+"""
+
+
+def test_rank_handle_with_one_rank(tmp_path):
+    """The torch-free one-process-per-GPU path on a one-GPU box: fxjps_rank_unique_id (ncclGetUniqueId), fxjps_create_rank
+    (ncclCommInitRank, a communicator of ONE rank), fxjps_set_grid_rank (ncclBroadcast in place), ncclCommCount == 1, same
+    plans as a plain handle; then fuxi_planner_amd.ranks.RankPlanner with a world of one.  No torch in the process."""
+    script = tmp_path / "rank1.py"
+    script.write_text(_RANK1 % {"root": ROOT})
+    try:
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL did not initialise within 240 s on this box")
+    if r.returncode != 0 and ("fxjps error -6" in r.stderr or "ncclCommInitRank" in r.stderr or "librccl" in r.stderr):
+        pytest.skip("RCCL is not usable on this box: " + r.stderr[-300:])
+    assert r.returncode == 0 and "RANK1-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "'rccl_ranks': 1" in r.stdout, r.stdout
+
+
 def test_in_library_multi_device_handle(planner):
     """fxjps_create(n_dev = 2): RCCL broadcast of the grid + contiguous shards inside the library (no torch)."""
     import fuxi_planner_amd as fx

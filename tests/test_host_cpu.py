@@ -137,3 +137,61 @@ def test_two_rank_gloo_shard_and_merge(tmp_path, oracle):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "MERGED-OK" in outs[0]
     assert "RANK 0 0 50" in outs[0] and "RANK 1 50 101" in outs[1]
+
+
+_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+assert "torch" not in sys.modules
+from fuxi_planner_amd.ranks import Rendezvous, RankPlanner
+from oracle import oracle
+
+class CheckerEngine(object):
+    def set_grid_occ(self, occ):
+        self.occ = np.array(occ, dtype=np.uint8)
+    def plan_batch(self, starts, goals, hchoice=2, max_path_len=None):
+        cells, ln, cost, _ = oracle.plan_batch(self.occ, starts, goals, hchoice, max_len=max_path_len or 512)
+        off = np.zeros(len(ln) + 1, dtype=np.int64); off[1:] = np.cumsum(np.maximum(ln, 0))
+        flat = np.concatenate([cells[q, :max(ln[q], 0)] for q in range(len(ln))] or [np.zeros((0, 2), np.int32)])
+        return off, flat, cost, ln
+
+rdv = Rendezvous.from_env()
+rank, world = rdv.rank, rdv.world
+rp = RankPlanner(rdv, device=0, engine_factory=lambda dev, r, w, uid: CheckerEngine())
+full = oracle.synth_grid(80, 120, 13, 0.25)
+assert rp.set_grid(full if rank == 0 else None) == (80, 120)
+assert np.array_equal(rp.engine.occ, full)
+s, g = oracle.synth_queries(full, 7, 100)
+lo, hi, off, cells, cost, status = rp.plan_local(s, g, 2, 256)
+merged = rp.gather(off, cells, cost, status)
+if rank == 0:
+    c1, l1, k1, _ = oracle.plan_batch(full, s, g, 2, max_len=256)
+    assert np.array_equal(merged[3], l1) and merged[2].tobytes() == k1.tobytes()
+    for q in range(100):
+        assert np.array_equal(merged[1][merged[0][q]:merged[0][q + 1]], c1[q, :max(l1[q], 0)])
+    print("MERGED-OK")
+else:
+    assert merged is None
+rdv.barrier()
+m = rdv.max([float(rank), 10.0 - rank])
+assert m == [float(world - 1), 10.0], m
+assert rdv.bcast("hello" if rank == 0 else None) == "hello"
+assert "torch" not in sys.modules                     # the whole path ran without it
+print("RANK", rank, lo, hi)
+rdv.close()
+"""
+
+
+def test_three_ranks_without_torch(tmp_path, oracle):
+    """fuxi_planner_amd.ranks: rendezvous over a TCP socket (what bench.py uses under a one-process-per-GPU launcher),
+    shard / merge with a checker engine, barrier and maximum -- three processes, no torch imported in any of them."""
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="3")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "MERGED-OK" in outs[0]
+    assert "RANK 0 0 33" in outs[0] and "RANK 1 33 66" in outs[1] and "RANK 2 66 100" in outs[2]
