@@ -64,6 +64,8 @@ busy)
   done;;
 stress)
   timeout 900 python tools/gpu_stress.py ${FX_STRESS_S:-240} ${FX_SEED:-4} > $OUT/stress.txt 2>&1; tail -4 $OUT/stress.txt; chk $OUT/stress.txt
+  FXJPS_DIRECT=0 timeout 900 python tools/gpu_stress.py $(( ${FX_STRESS_S:-240} * 2 / 3 )) $(( ${FX_SEED:-4} + 1 )) > $OUT/stress_hashed.txt 2>&1; tail -2 $OUT/stress_hashed.txt; chk $OUT/stress_hashed.txt
+  FXJPS_COOP=1 timeout 900 python tools/gpu_stress.py $(( ${FX_STRESS_S:-240} / 2 )) $(( ${FX_SEED:-4} + 2 )) > $OUT/stress_coop.txt 2>&1; tail -2 $OUT/stress_coop.txt; chk $OUT/stress_coop.txt
   timeout 900 python tools/gpu_stress_updates.py ${FX_STRESS_S:-240} ${FX_SEED:-4} > $OUT/stress_updates.txt 2>&1; tail -4 $OUT/stress_updates.txt; chk $OUT/stress_updates.txt;;
 esac
 done

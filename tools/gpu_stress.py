@@ -43,8 +43,11 @@ def main():
         kind, occ = make_map(rng)
         W, H = occ.shape
         n = int(rng.integers(50, 800))
-        if rng.random() < 0.08:  # now and then a batch large enough for the head launch (4 096 queries and more)
+        r_ = rng.random()
+        if r_ < 0.08:  # now and then a batch large enough for the head launch (4 096 queries and more)
             n = int(rng.integers(4096, 6000))
+        elif r_ < 0.2:  # ... and single calls (the one-launch path of nq == 1)
+            n = 1
         if rng.random() < 0.7 and (occ == 0).sum() >= 2:
             free = np.argwhere(occ == 0)
             s = free[rng.integers(0, len(free), n)].astype(np.int32); g = free[rng.integers(0, len(free), n)].astype(np.int32)
