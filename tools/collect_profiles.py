@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds the committed profile set of a round from gpurun_out/<tag>/prof_<workload>/summary.json (tools/gpu_round2.sh
+"""Builds the committed profile set of a round from gpurun_out/<tag>/prof_<workload>/summary.json (tools/gpu_round4.sh
 profiles): profiles/<round>_<workload>_kernel_stats.csv, profiles/<round>_<workload>_pmc.csv, profiles/<round>_bench_lines.json
 and profiles/hbm_traffic.json (FETCH_SIZE + WRITE_SIZE per step, tagged with the hash of the kernel source it was taken
 on: bench.py reports it as roofline.traffic only while that hash matches).
@@ -39,7 +39,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "prof_*", "summa
                       "L2_hit_rate": (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])) if c.get("TCC_HIT_sum") else None,
                       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum (separate passes) -- python3 bench.py --workload %s --steps 1 --warmup 0 --no-cpu-baseline" % w}
     kern = [r for r in ks if "k_search" in r.get("Name", "")]
-    algo = (b or {}).get("roofline", {}).get("algorithmic_bytes_per_launch")
+    algo = (b or {}).get("roofline", {}).get("algorithmic_bytes_per_step", (b or {}).get("roofline", {}).get("algorithmic_bytes_per_launch"))
     table.append((w, (b or {}).get("value"), (b or {}).get("ms_per_step"), kern[0]["AverageNs"] if kern else None, algo,
                   traffic.get(w, {}).get("hbm_bytes_per_launch"), c.get("SQ_INSTS_VALU"), c.get("SQ_INSTS_SALU")))
 traffic["_calibration"] = {"factors_counter_bytes_over_bytes_touched": calib, "source": "tools/calib_scatter.hip, profiles/r02_calib_scatter.txt",
