@@ -416,7 +416,7 @@ def main():
                 also["c4shard"] = brief(r)
             if cx.world == 1:
                 also["c1"] = measure_c1(cx)
-                r = measure(cx, "c3", 1, 0)  # BASELINE config 3: one timed step (100 000 queries on 4096^2, ~ 10 s), no warm-up
+                r = measure(cx, "c3", 1, 1)  # BASELINE config 3: one warm-up and one timed step (100 000 queries on 4096^2, ~ 10 s each)
                 if r:
                     also["c3"] = brief(r, ("retried",))
                     also["c3"]["resident_wavefronts"] = r["waves"]
