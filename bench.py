@@ -430,7 +430,8 @@ def main():
         if cx.world > 1 and cx.rdv is not None:
             rccl_ranks = ci["rccl_ranks"]
             collective = ("ncclBroadcast of the grid inside the library (fxjps_set_grid_rank), ncclCommCount = %d; rendezvous over TCP, no torch in the process" % rccl_ranks) \
-                if rccl_ranks else "none: the ranks share one device (rehearsal), the grid bytes travel over the rendezvous socket"
+                if rccl_ranks else ("none: RCCL did not come up (%s), the grid bytes travel over the rendezvous socket" % cx.sp.rccl_error if getattr(cx.sp, "rccl_error", None)
+                                    else "none: the ranks share one device (rehearsal), the grid bytes travel over the rendezvous socket")
         elif cx.world > 1:
             rccl_ranks = cx.world if backend == "nccl" else 0
             collective = "torch.distributed %s broadcast of the grid, %d ranks" % ("nccl (RCCL)" if backend == "nccl" else backend, cx.world)

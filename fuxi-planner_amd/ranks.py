@@ -139,11 +139,30 @@ class RankPlanner(object):
         if self.world > 1 and not self.host_broadcast:
             from .planner import Planner
             uid = rdv.bcast(Planner.rank_unique_id() if self.rank == 0 else None)
+        self.rccl_error = None
         if engine_factory is not None:
             self.engine = engine_factory(device, self.rank, self.world, uid)
+        elif self.host_broadcast:
+            from .planner import Planner
+            self.engine = Planner([device])
         else:
             from .planner import Planner
-            self.engine = Planner([device]) if self.host_broadcast else Planner.for_rank(device, self.rank, self.world, uid)
+            from ._lib import FxjpsError
+            err = None
+            try:
+                self.engine = Planner.for_rank(device, self.rank, self.world, uid)  # collective: ncclCommInitRank
+            except FxjpsError as e:
+                self.engine, err = None, str(e)
+            # every rank or none: a communicator that did not come up on one rank is of no use to the others -- the grid
+            # then travels over the rendezvous socket (speed of one 1 MiB message, never correctness), and the caller can
+            # see why (rccl_error)
+            errs = rdv.bcast(rdv.gather(err))
+            if any(e is not None for e in errs):
+                self.rccl_error = next(e for e in errs if e is not None)
+                if self.engine is not None:
+                    self.engine.close()
+                self.engine = Planner([device])
+                self.host_broadcast = True
         self.shape = None
 
     def set_grid(self, occ=None):
