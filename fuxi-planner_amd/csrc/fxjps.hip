@@ -125,6 +125,7 @@ struct DevCtx {
     DBuf<fx::BmWord> bm;
     DBuf<int> comp;
     DBuf<uint16_t> ci;
+    DBuf<uint16_t> jd;  // jump distances [PW][NS][8] (k_derive_jd)
     // search scratch (two pools: the regular one and the large retry one)
     DBuf<TEnt> tables[2];
     DBuf<FarEnt> far[2];
@@ -274,6 +275,7 @@ GridDev grid_of(const DevCtx& d) {
     G.bm = d.bm.p;
     G.ci = d.ci.p;
     G.nb8 = d.nb8.p;
+    G.jd = d.jd.p;
     G.comp = d.comp.p;
     G.W = d.W;
     G.H = d.H;
@@ -321,6 +323,10 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
             const long long nw = 4ll * G.DLINES * per;
             hipLaunchKernelGGL(fx::k_derive_diag, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G,
                                d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
+            // ... and the jump distances: the goal-free jumps themselves, from every cell along every direction, read off
+            // the scan words above (after an update: the entries whose old ray passes what the update can have changed)
+            const long long nj = (long long)d.PW * d.PH * 8;
+            hipLaunchKernelGGL(fx::k_derive_jd, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, d.stream, G, d.jd.p, dr);
         }
         HIPCHK(h, hipGetLastError());
     }
@@ -355,6 +361,7 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     HIPCHK(h, d.comp.ensure((size_t)W * H));
     HIPCHK(h, d.nb8.ensure((size_t)d.PW * d.NS));
     HIPCHK(h, d.ci.ensure((size_t)d.PW * d.NS));
+    HIPCHK(h, d.jd.ensure((size_t)d.PW * d.NS * 8));
     HIPCHK(h, d.bm.ensure((size_t)4 * d.LINES * d.WORDS + (size_t)4 * (d.PW + d.PH - 1) * d.WORDS));  // straight + diagonal scan lines
     return FXJPS_OK;
 }
@@ -1299,6 +1306,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.comp.release();
         d.nb8.release();
         d.ci.release();
+        d.jd.release();
         d.bm.release();
         for (int p = 0; p < 2; p++) {
             d.tables[p].release();
@@ -2311,7 +2319,8 @@ int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity
         case 2: src = d.comp.p; bytes = (size_t)d.W * d.H * sizeof(int); break;                    // component forest [W][H]
         case 3: src = d.nb8.p; bytes = (size_t)d.PW * d.NS; break;                                 // neighbour bytes [PW][NS]
         case 4: src = d.bm.p + (size_t)4 * d.LINES * d.WORDS; bytes = (size_t)4 * (d.PW + d.PH - 1) * d.WORDS * sizeof(fx::BmWord); break;  // diagonal scan words
-        default: return fail(h, FXJPS_E_ARG, "which must be 0 .. 4");
+        case 5: src = d.jd.p; bytes = (size_t)d.PW * d.NS * 8 * sizeof(uint16_t); break;              // jump distances [PW][NS][8]
+        default: return fail(h, FXJPS_E_ARG, "which must be 0 .. 5");
     }
     if (out_bytes) *out_bytes = (int64_t)bytes;
     if (!buf) return FXJPS_OK;

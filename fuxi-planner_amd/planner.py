@@ -358,7 +358,7 @@ class Planner(object):
     def debug_maps(self):
         """The derived device maps (fxjps_debug_read_maps): {"bm": uint64[4, LINES, WORDS, 2], "ci": uint16[W+2, H+2],
         "comp": int32[W, H] (union-find parent links), "nb8": uint8[W+2, H+2], "dbm": uint64[4, W+H+3, WORDS, 2] (the
-        diagonal scan words)}."""
+        diagonal scan words), "jd": uint16[W+2, H+2, 8] (the jump distances)}."""
         W, H = self.shape
         PW, PH = W + 2, H + 2
         NS = (PH + 63) & ~63
@@ -366,12 +366,12 @@ class Planner(object):
         WORDS = (LINES + 63) // 64
         out = {}
         for which, name, dt, shape in ((0, "bm", np.uint64, (4, LINES, WORDS, 2)), (1, "ci", np.uint16, (PW, NS)), (2, "comp", np.int32, (W, H)),
-                                       (3, "nb8", np.uint8, (PW, NS)), (4, "dbm", np.uint64, (4, PW + PH - 1, WORDS, 2))):
+                                       (3, "nb8", np.uint8, (PW, NS)), (4, "dbm", np.uint64, (4, PW + PH - 1, WORDS, 2)), (5, "jd", np.uint16, (PW, NS, 8))):
             a = np.zeros(shape, dtype=dt)
             nb = C.c_int64(0)
             self._chk(self._L.fxjps_debug_read_maps(self._h, which, a.ctypes.data_as(C.c_void_p), a.nbytes, C.byref(nb)))
             assert nb.value == a.nbytes, (name, nb.value, a.nbytes)
-            out[name] = a[:, :PH] if name in ("ci", "nb8") else a
+            out[name] = a[:, :PH] if name in ("ci", "nb8", "jd") else a
         # (lines the kernels neither write nor read -- the +-x scans have a line per padded y, the +-y scans per padded
         # x, the array has max(PW, PH) of each -- hold whatever the allocation held)
         out["bm"][0:2, PH:] = 0

@@ -273,7 +273,9 @@ int fxjps_debug_read_nbmask(fxjps_t* h, uint8_t* buf);
  * LINES = max(W, H) + 2, WORDS = ceil(LINES / 64)), 1 the cell infos (u16 [W + 2][NS], NS = H + 2 rounded up to 64; the
  * columns from H + 2 on are unused), 2 the component forest (int32 [W][H]: parent links, a root points at itself, -1
  * never free), 3 the neighbour bytes ([W + 2][NS]), 4 the diagonal scan words ([4][W + H + 3][WORDS] pairs of u64 {stop, occ}:
- * travel directions (+,+), (-,-), (+,-), (-,+), one line per diagonal, bit = padded x).  out_bytes receives the size;
+ * travel directions (+,+), (-,-), (+,-), (-,+), one line per diagonal, bit = padded x), 5 the jump distances (u16
+ * [W + 2][NS][8]: per cell and direction, steps to the cell that ends the goal-free jump | "it is a jump point" << 15;
+ * directions in the order (-1,-1), (-1,0), (-1,1), (0,-1), (0,1), (1,-1), (1,0), (1,1)).  out_bytes receives the size;
  * buf == NULL: the size only. */
 int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity_bytes, int64_t* out_bytes);
 

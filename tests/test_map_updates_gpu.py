@@ -25,7 +25,7 @@ def roots(par):
 def check_against_fresh(p, q, cur, tag):
     q.set_grid_occ(cur)
     a, b = p.debug_maps(), q.debug_maps()
-    for k in ("nb8", "bm", "ci", "dbm"):
+    for k in ("nb8", "bm", "ci", "dbm", "jd"):
         assert np.array_equal(a[k], b[k]), (tag, k, int((a[k] != b[k]).sum()))
     free = np.flatnonzero(cur.ravel() == 0)
     ra, rb = roots(a["comp"])[free], roots(b["comp"])[free]
