@@ -325,8 +325,13 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
                                d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
             // ... and the jump distances: the goal-free jumps themselves, from every cell along every direction, read off
             // the scan words above (after an update: the entries whose old ray passes what the update can have changed)
-            const long long nj = (long long)d.PW * d.PH * 8;
-            hipLaunchKernelGGL(fx::k_derive_jd, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, d.stream, G, d.jd.p, dr);
+            if (box) {
+                const long long nc = (long long)d.W * d.H;
+                hipLaunchKernelGGL(fx::k_update_jd, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, d.stream, G, d.jd.p, dr);
+            } else {
+                const long long nj = (long long)d.PW * d.PH * 8;
+                hipLaunchKernelGGL(fx::k_derive_jd, dim3((unsigned)((nj + 255) / 256)), dim3(256), 0, d.stream, G, d.jd.p, dr);
+            }
         }
         HIPCHK(h, hipGetLastError());
     }
