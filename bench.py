@@ -7,6 +7,9 @@ generator fuxi-planner_amd/synth.py):
 
     c2       BASELINE config 2 (default, the headline): 1024^2, 20 % obstacles, 10 000 queries, hchoice 2
     c2h1     the same with hchoice 1 (octile x10/x14)
+    c2pipe   config-2 batches back to back with two in flight (fuxi_planner_amd.replan.BatchPipeline: two planner
+             handles on the GPU take the batches in turn): sustained plans/s and submit-to-paths latency of a batch --
+             what the chip does with the headline's batches when it need not wait for each one's slowest query
     c3       BASELINE config 3: 4096^2, 100 000 queries
     c4shard  one GPU's share of BASELINE config 4: 1024^2, 125 000 queries
     c4       BASELINE config 4 itself: 1 000 000 queries split over the N GPUs (strong scaling; N = 1: all of them)
@@ -29,8 +32,8 @@ N > 1, two ways (contiguous query shards, one broadcast of the grid o
 
 Prints ONE JSON line on rank 0 (the driver contract) with `roofline` (HBM bound, algorithmic bytes / HIP-event kernel
 time), at N = 1 `cpu_baseline` (the C oracle on the host cores, bounded sample), and -- default workload only --
-`config.also`: the other BASELINE workloads measured right behind the timed region of the headline (c4shard and c5pipe
-at N = 1; the 1 M queries of c4 split N ways at N > 1), so that they are in the driver's record too.
+`config.also`: the other BASELINE workloads measured right behind the timed region of the headline (c4shard, c1, c3,
+c5pipe and c2pipe at N = 1; the 1 M queries of c4 split N ways at N > 1), so that they are in the driver's record too.
 """
 import argparse
 import hashlib
@@ -46,7 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-DEFAULT_STEPS = {"c5pipe": (600, 16)}  # workload -> (steps, warmup); everything else 5 / 2
+DEFAULT_STEPS = {"c5pipe": (600, 16), "c2pipe": (24, 6)}  # workload -> (steps, warmup); everything else 5 / 2
 
 
 def kernel_src_sha16():
@@ -116,6 +119,14 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         else:
             planner.set_queries(starts, goals, hchoice, mpl)
 
+    if wl.get("batches_in_flight"):
+        if cx.world > 1 or cx.gpus > 1:
+            raise SystemExit("c2pipe is a single-GPU workload")
+        if frames_in_flight > 0:
+            wl["batches_in_flight"] = frames_in_flight
+        from fuxi_planner_amd.replan import BatchPipeline
+        pipe = BatchPipeline(cx.dev_index, int(wl["batches_in_flight"]), occ)
+
     def step(i):
         if streaming:  # one call per frame: cell updates + map rebuild + search of the persistent queries
             off, cells, cost, status = planner.replan_frame(*frames[i])
@@ -130,14 +141,16 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     waves = waves_short = 0
     launches = 1
     lat = None
-    if pipe is not None:  # frames in flight: submit them all, the pipeline hands each to the next free handle
-        for f in [pipe.submit(*frames[i]) for i in range(warmup)]:
+    if pipe is not None:  # frames / batches in flight: submit them all, the pipeline hands each to the next free handle
+        def job(i):
+            return frames[i] if streaming else (starts, goals, hchoice, mpl)
+        for f in [pipe.submit(*job(i)) for i in range(warmup)]:
             f.result()
         t_sub, t_done, futs = [], {}, []
         t0 = time.perf_counter()
         for i in range(steps):
             t_sub.append(time.perf_counter())  # (submit blocks while the handle whose turn it is still plans)
-            f = pipe.submit(*frames[warmup + i])
+            f = pipe.submit(*job(warmup + i))
             f.add_done_callback(lambda _f, _i=i: t_done.__setitem__(_i, time.perf_counter()))
             futs.append(f)
         res = [f.result() for f in futs]
@@ -225,7 +238,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         # (what the frames' overlapping launches move per second: algorithmic bytes per frame / frame period -- a rate of
         # the pipeline, not of a kernel)
         out["pipeline_GBps"] = algo / (frame_period_ms * 1e-3) / 1e9 if algo else None
-        out["frames_in_flight"] = int(wl["frames_in_flight"])
+        out["frames_in_flight"] = int(wl.get("frames_in_flight") or wl["batches_in_flight"])
         out["latency_ms"] = {"mean": float(lat.mean()), "p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                              "max": float(lat.max()), "frames": int(len(lat))}
     return out
@@ -307,19 +320,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c2h1", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5local4k", "c5pipe"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c2h1", "c2pipe", "c3", "c4shard", "c4", "c5", "c5low", "c5local", "c5local4k", "c5pipe"])
     ap.add_argument("--inlib", action="store_true", help="one process, all GPUs through fxjps_create(n_dev = N) (the default when "
                     "bench.py is not started by torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="default workload: skip the config.also measurements")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe: planner handles taking the frames in turn (0: the workload's)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="c5pipe / c2pipe: planner handles taking the frames / batches in turn (0: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries timed on the host cores (0: the workload's default)")
     ap.add_argument("--py-sample", type=int, default=64, help="queries timed with the pure-Python restatement of the reference (0: none)")
     a = ap.parse_args()
     d_steps, d_warm = DEFAULT_STEPS.get(a.workload, (5, 2))
     a.steps = d_steps if a.steps is None else a.steps
     a.warmup = d_warm if a.warmup is None else a.warmup
-    if a.workload == "c5pipe":
+    if a.workload in ("c5pipe", "c2pipe"):
         # one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run one
         # after the other; read by the HIP runtime when it initialises (nothing has touched the GPU yet)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -342,6 +355,10 @@ def main():
 
     with open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")) as f:
         cx.WL = json.load(f)
+    # (config 2 itself, batch after batch with several in flight: the same grid, the same 10 000 queries per batch)
+    cx.WL["c2pipe"] = dict(cx.WL["c2"], batches_in_flight=2, describe=cx.WL["c2"]["describe"].replace(
+        "BASELINE config 2:", "BASELINE config 2, batches back to back with 2 in flight (2 planner handles on the GPU take them in turn; "
+        "every batch is the same fxjps_plan_batch call):"))
 
     cx.torch = cx.dist = cx.sp = cx.rdv = None
     # One process per GPU (WORLD_SIZE > 1, e.g. under torch.distributed.run): by default NO torch in the process -- the
@@ -495,6 +512,13 @@ def main():
                 out["roofline"].update({"achieved": None, "frac": None, "kernel_ms": None, "pipeline_GBps": m["pipeline_GBps"]})
                 out["roofline"]["note"] = ("the launches of the frames in flight overlap: there is no kernel time and no roofline fraction of a "
                                            "kernel; pipeline_GBps = algorithmic bytes per frame / frame period; " + out["roofline"]["note"])
+        if "latency_ms" in m and not m["streaming"]:  # batches in flight (c2pipe)
+            out["config"].update({"batches_in_flight": m["frames_in_flight"], "planner_handles": m["frames_in_flight"],
+                                  "submit_to_paths_latency_ms": m["latency_ms"], "batch_period_ms": m["frame_period_ms"],
+                                  "parallelism": "%d planner handles on one GPU take the batches in turn" % m["frames_in_flight"]})
+            out["roofline"].update({"achieved": None, "frac": None, "kernel_ms": None, "pipeline_GBps": m["pipeline_GBps"]})
+            out["roofline"]["note"] = ("the launches of the batches in flight overlap: there is no kernel time and no roofline fraction of a "
+                                       "kernel; pipeline_GBps = algorithmic bytes per batch / batch period; " + out["roofline"]["note"])
         if a.workload == "c2" and not a.no_also and a.gpus == 1 and cx.world == 1:
             # config 5 with frames in flight, in a child process of its own (its eight handles want their own hardware
             # queues -- an environment variable the HIP runtime reads when it starts -- and their own memory)
@@ -516,6 +540,22 @@ def main():
                     also["c5pipe"] = {"error": (r.stderr or r.stdout)[-300:]}
             except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
                 also["c5pipe"] = {"error": repr(e)[:300]}
+            # ... and config 2 itself, batch after batch with two in flight: what the chip does with the headline's batches
+            # when it need not wait for each one's slowest query
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c2pipe", "--no-cpu-baseline"],
+                                   capture_output=True, text=True, timeout=200)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode == 0 and line:
+                    j = json.loads(line[-1])
+                    also["c2pipe"] = {"value": j["value"], "unit": "plans/s", "steps": j["steps"], "queries_per_step": j["config"]["queries_per_step"],
+                                      "batch_period_ms": j["config"]["batch_period_ms"], "kernel_ms": None, "frac": None,
+                                      "pipeline_GBps": j["roofline"]["pipeline_GBps"], "planner_handles": j["config"]["planner_handles"],
+                                      "submit_to_paths_latency_ms": j["config"]["submit_to_paths_latency_ms"]}
+                else:
+                    also["c2pipe"] = {"error": (r.stderr or r.stdout)[-300:]}
+            except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+                also["c2pipe"] = {"error": repr(e)[:300]}
         if also:
             out["config"]["also"] = also
         if cx.world == 1 and not cx.inlib and not a.no_cpu_baseline:

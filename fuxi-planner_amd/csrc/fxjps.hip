@@ -802,10 +802,15 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
     HIPCHK(h, hipSetDevice(d.dev));
     const int64_t nq = d.nq;
     if (nq == 0) return FXJPS_OK;
-    HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+    // The result lengths are copied AFTER the host has seen the search finish, not queued behind it: a copy that waits
+    // in the copy engine's queue for a kernel holds up every copy queued after it -- the input copies of another handle's
+    // next batch on this device among them, and with them that batch's launch (two handles planning config-2 batches in
+    // turn ran strictly one after the other: tools/copy_timeline.py).
     DBG("waiting for the search kernel");
     HIPCHK(h, hipStreamSynchronize(d.stream));
     DBG("search kernel done");
+    HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(h, hipStreamSynchronize(d.stream));
     float ms = 0;
     d.head_ms = d.batch_ms = 0;
     if (d.launches > 0) {
@@ -831,6 +836,7 @@ int finish_shard(fxjps* h, DevCtx& d, int hchoice, int max_len) {
         HIPCHK(h, hipStreamSynchronize(d.stream));  // `redo` is pageable host memory
         rc = launch_search(h, d, 1, d.d_redo.p, (uint32_t)redo.size(), hchoice, max_len, d.mode != 0);
         if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(d.stream));  // (as above: no copy waits in the engine's queue for a search)
         HIPCHK(h, hipMemcpyAsync(d.h_len.p, d.d_len.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
         HIPCHK(h, hipStreamSynchronize(d.stream));
         HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));

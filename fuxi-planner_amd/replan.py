@@ -112,3 +112,61 @@ class FramePipeline(object):
 
     def __exit__(self, *exc):
         self.close()
+
+
+class BatchPipeline(object):
+    """Independent query batches on one resident grid with several batches in flight.
+
+    A batch of config-2 size ends with the latency of its slowest queries: for the last third of
+    its 68 ms the chip is nearly idle.  Batches do not depend on each other, so K planner handles on one device (own
+    grid copy, own scratch -- a K-th of the device's each --, own streams) take them in turn; every result is what
+    `Planner.plan_batch` returns for that batch (same library call, same kernels).  A batch's latency grows (it shares
+    the chip), the rate is what the chip's vector units allow.
+
+        pipe = BatchPipeline(0, 3, occ)
+        futures = [pipe.submit(starts, goals) for starts, goals in batches]   # blocks only while its handle is busy
+        for f in futures: offsets, cells, cost, status = f.result()
+    """
+
+    def __init__(self, device, k, occ):
+        from .planner import Planner
+        self.k = int(k)
+        self.planners = [Planner([device]) for _ in range(self.k)]
+        for p in self.planners:
+            p.set_memory_share(self.k)
+            p.set_grid_occ(occ)
+        self._busy = [None] * self.k
+        self._pool = ThreadPoolExecutor(max_workers=self.k)
+        self._n = 0
+
+    def submit(self, starts, goals, hchoice=2, max_path_len=None):
+        """Queue one batch.  Blocks only while the handle whose turn it is still plans its previous batch (whose failure,
+        if any, is the caller's through that batch's own future)."""
+        j = self._n % self.k
+        if self._busy[j] is not None:
+            try:
+                self._busy[j].result()
+            except BaseException:
+                pass
+        self._n += 1
+        self._busy[j] = self._pool.submit(self.planners[j].plan_batch, starts, goals, hchoice, max_path_len)
+        return self._busy[j]
+
+    def close(self):
+        try:
+            for f in self._busy:
+                if f is not None:
+                    try:
+                        f.result()
+                    except BaseException:
+                        pass
+        finally:
+            self._pool.shutdown(wait=True)
+            for p in self.planners:
+                p.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -492,6 +492,22 @@ def test_frames_in_flight(oracle):
             assert_same(f.result(), want[fr])
 
 
+def test_batches_in_flight(oracle):
+    """BatchPipeline (bench.py --workload c2pipe): three planner handles on the GPU take independent batches on one grid in
+    turn; every batch's result is the oracle's, whichever handle planned it and whatever ran beside it."""
+    from fuxi_planner_amd import synth
+    from fuxi_planner_amd.replan import BatchPipeline
+    occ = synth.synth_grid(512, 400, 41, 0.20)
+    batches = []
+    for b in range(7):
+        s, g = synth.synth_queries(occ, 100 + b, 700 + 50 * b)
+        batches.append((s, g, 1 + b % 2))
+    with BatchPipeline(0, 3, occ) as pipe:
+        futs = [pipe.submit(s, g, h, 1024) for s, g, h in batches]
+        for (s, g, h), f in zip(batches, futs):
+            assert_same(f.result(), oracle_csr(oracle, occ, s, g, h, 1024))
+
+
 def test_frames_in_flight_config5_eight_handles(oracle):
     """BASELINE config 5 the way bench.py --workload c5pipe runs it: 1024^2, the 1 000 persistent queries, 10 % of the cells
     toggled per frame (SURVEY 8d stream), EIGHT planner handles taking the frames in turn -- 48 frames, every path of

@@ -135,3 +135,48 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
     FakePlanner.made[1].replan_frame = orig
     pipe.close()
     assert all(p.closed for p in FakePlanner.made)
+
+
+def test_batch_pipeline_hands_the_batches_out_in_turn(monkeypatch):
+    """BatchPipeline (host logic, no GPU): batch b goes to handle b % K, every handle has the grid, a handle is used by
+    one thread at a time, every future carries its own batch's answer."""
+    import threading
+    import fuxi_planner_amd.planner as planner_mod
+    from fuxi_planner_amd.replan import BatchPipeline
+
+    class FakePlanner(object):
+        made = []
+
+        def __init__(self, devices):
+            self.lock = threading.Lock()
+            self.batches = []
+            self.closed = False
+            FakePlanner.made.append(self)
+
+        def set_memory_share(self, k):
+            self.share = k
+
+        def set_grid_occ(self, occ):
+            self.grid = occ.copy()
+
+        def plan_batch(self, starts, goals, hchoice=2, max_path_len=None):
+            assert self.lock.acquire(blocking=False), "a handle is used by one thread at a time"
+            self.batches.append(int(starts[0, 0]))
+            out = (int(starts[0, 0]), int(self.grid.sum()), hchoice, max_path_len)
+            self.lock.release()
+            return out
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(planner_mod, "Planner", FakePlanner)
+    occ = (np.random.default_rng(4).random((10, 7)) < 0.3).astype(np.uint8)
+    for k in (1, 2, 4):
+        FakePlanner.made = []
+        with BatchPipeline(0, k, occ) as pipe:
+            futs = [pipe.submit(np.full((3, 2), b, np.int32), np.zeros((3, 2), np.int32), 1 + b % 2, 64) for b in range(11)]
+            got = [f.result() for f in futs]
+        assert got == [(b, int(occ.sum()), 1 + b % 2, 64) for b in range(11)]
+        assert len(FakePlanner.made) == k and all(p.closed and p.share == k for p in FakePlanner.made)
+        for j, p in enumerate(FakePlanner.made):
+            assert p.batches == list(range(j, 11, k))
