@@ -520,7 +520,7 @@ def main():
             out["roofline"]["note"] = ("the launches of the batches in flight overlap: there is no kernel time and no roofline fraction of a "
                                        "kernel; pipeline_GBps = algorithmic bytes per batch / batch period; " + out["roofline"]["note"])
         if a.workload == "c2" and not a.no_also and a.gpus == 1 and cx.world == 1:
-            # config 5 with frames in flight, in a child process of its own (its eight handles want their own hardware
+            # config 5 with frames in flight, in a child process of its own (its handles want their own hardware
             # queues -- an environment variable the HIP runtime reads when it starts -- and their own memory)
             cx.planner.close()
             cx.planner = None

@@ -45,7 +45,7 @@ WORKLOADS = {
                       describe="streaming replan at the size of config 3: 4096x4096 grid (seed 2), per frame one 64x64 window re-observed, 1000 persistent "
                                "queries (qseed 5): the read-set instantiation on hashed tables, partial map rebuilds, united component labels"),
 }
-PIPE_FRAMES = 8  # c5pipe: config 5 with this many frames in flight (same frames, same counts: derived from c5)
+PIPE_FRAMES = 12  # (round 4: 8; measured 5 .. 16) c5pipe: config 5 with this many frames in flight (same frames, same counts: derived from c5)
 NT = min(os.cpu_count() or 8, 256)
 
 
