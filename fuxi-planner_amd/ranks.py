@@ -32,7 +32,7 @@ def _send(sock, obj):
     sock.sendall(struct.pack("<Q", len(b)) + b)
 
 
-def _recv(sock):
+def _recv(sock, limit=None):
     def exact(n):
         buf = bytearray()
         while len(buf) < n:
@@ -42,46 +42,90 @@ def _recv(sock):
             buf += chunk
         return bytes(buf)
     (n,) = struct.unpack("<Q", exact(8))
+    if limit is not None and n > limit:
+        raise ValueError("rendezvous message of %d bytes where at most %d were expected" % (n, limit))
     return pickle.loads(exact(n))
 
 
+_HELLO, _WELCOME = "fxjps-rendezvous-hello", "fxjps-rendezvous-welcome"
+_PORT_STEPS = (0, 6, 12, 100)  # the port asked for, then these offsets from it: somebody else may be listening there
+
+
 class Rendezvous(object):
-    """A star of TCP connections to rank 0: broadcast / gather of small Python objects, barrier, maximum."""
+    """A star of TCP connections to rank 0: broadcast / gather of small Python objects, barrier, maximum.
+
+    Rank 0 listens on `port`; if that port is taken, on the next of a short fixed list of offsets from it.  The other
+    ranks try the same list in the same order and know rank 0 by its answer to their greeting, so a foreign listener on
+    one of the ports (it does not answer, or answers something else) is passed over."""
 
     def __init__(self, rank, world, addr="127.0.0.1", port=29600, timeout=120.0):
         self.rank, self.world = int(rank), int(world)
         self.peers = []   # rank 0: sockets to ranks 1 .. world - 1, in rank order
         self.sock = None  # other ranks: the socket to rank 0
+        self.port = None  # the port the star was built on
         if self.world == 1:
             return
+        ports = [int(port) + d for d in _PORT_STEPS]
         if self.rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, int(port)))
+            srv, err = None, None
+            for pt in ports:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    srv.bind((addr, pt))
+                    self.port = pt
+                    break
+                except OSError as e:
+                    err = e
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise err
             srv.listen(self.world)
             srv.settimeout(timeout)
             got = {}
             while len(got) < self.world - 1:
                 c, _ = srv.accept()
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(10.0)
+                try:
+                    hello = _recv(c, limit=4096)
+                    if not (isinstance(hello, tuple) and len(hello) == 3 and hello[0] == _HELLO and int(hello[2]) == self.world
+                            and 1 <= int(hello[1]) < self.world and int(hello[1]) not in got):
+                        raise ValueError("not a rank of this run")
+                    _send(c, (_WELCOME, self.world))
+                except (OSError, ValueError, TypeError, pickle.UnpicklingError, EOFError, struct.error):
+                    c.close()  # (somebody else's connection)
+                    continue
                 c.settimeout(None)  # (an accepted socket is blocking whatever the listener's timeout is; say so)
-                r = _recv(c)
-                got[int(r)] = c
+                got[int(hello[1])] = c
             srv.close()
             self.peers = [got[r] for r in range(1, self.world)]
         else:
             t0 = time.time()
-            while True:
-                try:
-                    s = socket.create_connection((addr, int(port)), timeout=5.0)
-                    break
-                except OSError:
+            s = None
+            while s is None:
+                for pt in ports:
+                    try:
+                        c = socket.create_connection((addr, pt), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        c.settimeout(5.0)
+                        _send(c, (_HELLO, self.rank, self.world))
+                        ans = _recv(c, limit=4096)
+                        if isinstance(ans, tuple) and len(ans) == 2 and ans[0] == _WELCOME and int(ans[1]) == self.world:
+                            s, self.port = c, pt
+                            break
+                        c.close()
+                    except (OSError, ValueError, TypeError, pickle.UnpicklingError, EOFError, struct.error):
+                        c.close()  # (not rank 0: a foreign listener, or rank 0 of another run)
+                if s is None:
                     if time.time() - t0 > timeout:
-                        raise
+                        raise TimeoutError("rendezvous: rank 0 did not answer on %s ports %s within %.0f s" % (addr, ports, timeout))
                     time.sleep(0.05)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(None)
-            _send(s, self.rank)
             self.sock = s
 
     @classmethod

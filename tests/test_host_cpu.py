@@ -195,3 +195,50 @@ def test_three_ranks_without_torch(tmp_path, oracle):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "MERGED-OK" in outs[0]
     assert "RANK 0 0 33" in outs[0] and "RANK 1 33 66" in outs[1] and "RANK 2 66 100" in outs[2]
+
+
+def test_rendezvous_passes_over_a_taken_port():
+    """MASTER_PORT + 1 may belong to somebody else: rank 0 then listens on the next port of the fixed list, and the other
+    ranks know it by its answer to their greeting -- a foreign listener that accepts and says nothing (or something else)
+    is passed over."""
+    import socket
+    import threading
+    from fuxi_planner_amd.ranks import Rendezvous
+    base = 29871
+    foreign = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    foreign.bind(("127.0.0.1", base))
+    foreign.listen(8)
+    stop = threading.Event()
+
+    def serve():  # accepts, answers nonsense, hangs up
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+            except OSError:
+                continue
+            try:
+                c.sendall(b"HTTP/1.0 400 no\r\n\r\n")
+            except OSError:
+                pass
+            c.close()
+
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    out = {}
+
+    def rank(r):
+        rdv = Rendezvous(r, 3, "127.0.0.1", base, timeout=60.0)
+        out[r] = (rdv.port, rdv.bcast("token" if r == 0 else None), rdv.max([float(r)]))
+        rdv.barrier()
+        rdv.close()
+
+    ths = [threading.Thread(target=rank, args=(r,)) for r in range(3)]
+    [t.start() for t in ths]
+    [t.join(timeout=90) for t in ths]
+    stop.set()
+    th.join(timeout=5)
+    foreign.close()
+    assert sorted(out) == [0, 1, 2]
+    assert all(v == (base + 6, "token", [2.0]) for v in out.values()), out
