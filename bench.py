@@ -382,7 +382,9 @@ def main():
     if cx.world > 1 and backend == "ranks":
         from fuxi_planner_amd.ranks import RankPlanner, Rendezvous
         cx.rdv = Rendezvous.from_env()
-        cx.sp = RankPlanner(cx.rdv, device=cx.dev_index, host_broadcast=one_dev)
+        # (FXJPS_BENCH_TRY_RCCL=1 with FXJPS_BENCH_ONE_DEVICE=1: the ranks ask RCCL all the same -- it refuses ranks that share a
+        # device --, which rehearses the agreement of RankPlanner on "every rank or none" and its way over the socket)
+        cx.sp = RankPlanner(cx.rdv, device=cx.dev_index, host_broadcast=one_dev and not os.environ.get("FXJPS_BENCH_TRY_RCCL"))
         cx.planner = cx.sp.engine
         if one_dev:
             cx.planner.set_memory_share(cx.world)  # (the rehearsal's ranks share device 0: a host that does that says so)
