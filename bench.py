@@ -92,9 +92,10 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     n_units = cx.gpus
     planner = cx.planner
     occ = synth.synth_grid(W, H, wl["grid_seed"], wl["p"])  # every rank needs it to draw its queries
+    piped = bool(wl.get("frames_in_flight") or wl.get("batches_in_flight"))  # (the pipeline's own handles hold the grid: K of them, not K + 1)
     if cx.world > 1:
         cx.sp.set_grid(occ if cx.rank == 0 else None)  # one RCCL broadcast of W*H bytes over xGMI
-    else:
+    elif not piped:
         planner.set_grid_occ(occ)  # in-library N > 1: H2D to the first device + ncclBroadcast inside the library
     if strong:
         lo, hi = shard_bounds(nq, cx.rank, cx.world) if cx.world > 1 else (0, nq)
@@ -127,11 +128,14 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         from fuxi_planner_amd.replan import BatchPipeline
         pipe = BatchPipeline(cx.dev_index, int(wl["batches_in_flight"]), occ)
 
+    last = {}
+
     def step(i):
         if streaming:  # one call per frame: cell updates + map rebuild + search of the persistent queries
             off, cells, cost, status = planner.replan_frame(*frames[i])
         else:
             off, cells, cost, status = planner.plan_batch(starts, goals, hchoice, mpl)  # blocking: results are in host memory
+        last["res"] = (off, cells, cost, status)  # (what the CPU legs check, cell for cell: outside the timed region)
         return status, planner.timing()
 
     kernel_ms, per_ctx = [], None
@@ -158,6 +162,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         if any((r[3] < 0).any() for r in res):
             raise SystemExit("bench: queries failed")
         status = res[-1][3]  # (the last frame's: the CPU baseline below plans on that frame's grid)
+        last["res"] = res[-1]
         direct = 1
         kernel_ms = [float("nan")]  # (the launches of the frames overlap: there is no kernel time; see frame_period_ms)
         frame_period_ms = elapsed / steps * 1e3
@@ -227,6 +232,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         "frac": achieved / HBM_PEAK_GBS if achieved else None, "retried": int(retried), "reused": reused, "direct": direct,
         "waves": waves, "waves_short": waves_short, "launches": launches, "wl": wl, "frames": frames,
         "launch_ms": ({"head": float(np.mean(head_ms)), "batch": float(np.mean(batch_ms))} if launches == 2 and head_ms else None),
+        "last": last.get("res"),
         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and name not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
     }
     if streaming:
@@ -335,7 +341,8 @@ def main():
     if a.workload in ("c5pipe", "c2pipe"):
         # one hardware queue per planner handle, or the persistent search kernels of handles that share a queue run one
         # after the other; read by the HIP runtime when it initialises (nothing has touched the GPU yet)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        from fuxi_planner_amd.replan import configure_hw_queues
+        configure_hw_queues()
 
     cx = Ctx()
     cx.rank = int(os.environ.get("RANK", "0"))
@@ -411,6 +418,8 @@ def main():
     cx.sync = sync
 
     if a.workload == "c1":  # single calls: a latency, reported on its own line
+        if cx.world > 1 or a.gpus > 1:
+            raise SystemExit("c1 is a single-GPU, single-process workload (one query per call)")
         r = measure_c1(cx)
         print(json.dumps({"metric": "start->goal plans/sec, one query per call, 256x256 canvas of a reference map", "value": r["value"], "unit": "plans/s",
                           "n_gpus": 1, "steps": 20, "warmup": 1, "ms_per_step": r["us_per_call"] / 1e3, "higher_is_better": True, "scaling": "weak",
@@ -430,10 +439,15 @@ def main():
                 d[k] = r[k]
             return d
         if a.gpus == 1:
-            r = measure(cx, "c4shard", 2, 1)
+            r = measure(cx, "c4shard", 3, 1)
             if r:
                 also["c4shard"] = brief(r)
             if cx.world == 1:
+                # BASELINE config 4 itself on ONE GPU: the anchor of the strong-scaling curve (at N > 1 the same 1 M queries
+                # are split N ways, below)
+                r = measure(cx, "c4", 1, 1)
+                if r:
+                    also["c4"] = brief(r, ("kernel_ms_per_device",))
                 also["c1"] = measure_c1(cx)
                 r = measure(cx, "c3", 1, 1)  # BASELINE config 3: one warm-up and one timed step (100 000 queries on 4096^2, ~ 10 s each)
                 if r:
@@ -567,9 +581,14 @@ def main():
             nth = min(cores, wl.get("cpu_threads", cores))
             g_now = m["grid_now"] if m["grid_now"] is not None else m["occ"]  # (streaming: the grid after the last frame)
             tc = time.perf_counter()
-            _, ol, _, _ = oracle.plan_batch(g_now, m["starts"][:ns], m["goals"][:ns], m["hchoice"], literal=False, max_len=m["mpl"], nthreads=nth)
+            oc, ol, ocost, _ = oracle.plan_batch(g_now, m["starts"][:ns], m["goals"][:ns], m["hchoice"], literal=False, max_len=m["mpl"], nthreads=nth)
             dt = time.perf_counter() - tc
-            assert np.array_equal(ol, m["status"][:ns])
+            # the CPU leg is the checker too: lengths, float64 costs as bytes, every cell of every path
+            off_g, cells_g, cost_g, _ = m["last"]
+            assert np.array_equal(ol, m["status"][:ns]), "the C port disagrees with the GPU on path lengths"
+            assert ocost.tobytes() == cost_g[:ns].tobytes(), "the C port disagrees with the GPU on a cost (float64 bytes)"
+            keep = np.arange(oc.shape[1])[None, :] < np.maximum(ol, 0)[:, None]
+            assert np.array_equal(oc[keep], cells_g[:off_g[ns]]), "the C port disagrees with the GPU on the cells of a path"
             out["cpu_baseline"] = {"value": ns / dt, "unit": "plans/s", "cores": nth, "kind": "port",
                                    "sample": "first %d queries of the same batch, oracle/jps_oracle.c (-O2), "
                                              "%d pthreads, %.1f s" % (ns, nth, dt)}
@@ -581,8 +600,11 @@ def main():
                 npy = min(a.py_sample, m["n_local"])
                 if npy > 0:
                     nproc = min(os.cpu_count() or 1, npy)
-                    lens, _, wall, cpu_s = jps_python.timed_batch(m["occ"], m["starts"][:npy], m["goals"][:npy], m["hchoice"], nproc)
+                    lens, pcost, wall, cpu_s = jps_python.timed_batch(m["occ"], m["starts"][:npy], m["goals"][:npy], m["hchoice"], nproc)
                     assert lens == [max(int(v), 0) for v in m["status"][:npy]], "the Python restatement disagrees with the GPU on path lengths"
+                    for q in range(npy):  # (its printed cost, jps1.py:207, is the float64 the GPU returns -- bit for bit)
+                        if lens[q] > 0:
+                            assert np.float64(pcost[q]).tobytes() == np.float64(cost_g[q]).tobytes(), "the Python restatement disagrees with the GPU on a cost"
                     out["cpu_baseline_python"] = {"value": npy / wall, "unit": "plans/s", "cores": nproc, "kind": "port",
                                                   "per_core_plans_per_s": npy / cpu_s,
                                                   "sample": "first %d queries of the same batch, oracle/jps_python.py (pure Python restatement with the "

@@ -13,7 +13,9 @@ Q_NOPATH, Q_PATH_TOO_LONG, Q_BAD_START, Q_CAPACITY = 0, -1, -2, -3
 BACKEND_HIP = 1
 
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
-SYMBOLS = ("fxjps_version", "fxjps_device_count", "fxjps_create", "fxjps_rank_unique_id", "fxjps_create_rank", "fxjps_set_grid_rank", "fxjps_destroy", "fxjps_last_error",
+VERSION = 500  # FXJPS_VERSION of include/fxjps.h
+SYMBOLS = ("fxjps_version", "fxjps_timing_size", "fxjps_last_timing_sized", "fxjps_rank_preflight", "fxjps_reserve_grid",
+           "fxjps_device_count", "fxjps_create", "fxjps_rank_unique_id", "fxjps_create_rank", "fxjps_set_grid_rank", "fxjps_destroy", "fxjps_last_error",
            "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
            "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask", "fxjps_debug_read_maps", "fxjps_debug_counters", "fxjps_debug_qstat",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst", "fxjps_waypoint_ccst_batch", "fxjps_waypoint_st_batch")
@@ -66,6 +68,17 @@ def load():
     p_u8 = C.POINTER(C.c_uint8)
     p_f64 = C.POINTER(C.c_double)
     L.fxjps_version.restype = C.c_int
+    L.fxjps_timing_size.restype = C.c_int
+    # (neither call touches a device)
+    if L.fxjps_version() != VERSION or L.fxjps_timing_size() != C.sizeof(Timing):
+        raise FxjpsError(E_ARG, "%s is version %d with a %d-byte timing record; this binding is for version %d / %d bytes: rebuild it"
+                         % (LIB_PATH, L.fxjps_version(), L.fxjps_timing_size(), VERSION, C.sizeof(Timing)))
+    L.fxjps_last_timing_sized.restype = C.c_int
+    L.fxjps_last_timing_sized.argtypes = [vp, vp, C.c_int64]
+    L.fxjps_rank_preflight.restype = C.c_int
+    L.fxjps_rank_preflight.argtypes = [C.c_int]
+    L.fxjps_reserve_grid.restype = C.c_int
+    L.fxjps_reserve_grid.argtypes = [vp, C.c_int32, C.c_int32]
     L.fxjps_device_count.restype = C.c_int
     L.fxjps_create.restype = C.c_int
     L.fxjps_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]

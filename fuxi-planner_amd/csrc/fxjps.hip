@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -107,6 +108,10 @@ struct DevCtx {
     size_t mem_total = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
+    hipStream_t stream_rest = nullptr;  // FXJPS_HEAD_XCDS=n: stream_solo may only use the CUs of n XCDs (an L2 of their own), and the
+                                        // batch's launch, while a head launch runs beside it, goes to this stream, which may only use the others
+    int n_cu_rest = 0;                  // ... and how many those are
+    hipEvent_t ev_rest1 = nullptr;
     uint32_t* solo_started = nullptr;   // pinned host word: blocks of such launches that have started (only ever counts up)
     uint32_t solo_target = 0;           // ... and how many have been launched
     int solo_timeouts = 0;              // waits for that counter that ran into their 5 ms bound, since the handle was created
@@ -152,6 +157,11 @@ struct DevCtx {
     DBuf<uint8_t> d_upd_val, d_upd_chg;
     DBuf<int> d_owner;        // [W][H], -1 at rest: which entry of an update list decides a cell it names several times
     bool owner_ready = false;
+    // a partial rebuild's changed cells (k_derive_cellinfo -> k_jd_walk): marks [PW][NS], zero at rest; their list; counters
+    DBuf<uint8_t> d_chgmap;
+    DBuf<uint32_t> d_chglist;
+    DBuf<unsigned int> d_chgcnt;
+    bool chg_ready = false;
     // what the cell updates since the last rebuild of the derived maps can have changed: the box, in padded
     // coordinates, of the updated cells and their neighbours; whether the component labels need the full relabelling (a
     // large update, or 64 small ones, which are united into the existing labels as they come: k_ccl_update)
@@ -184,6 +194,7 @@ struct DevCtx {
 struct fxjps {
     std::vector<DevCtx> devs;
     std::string err;
+    std::mutex err_mu;  // the shards of a multi-device batch run on one host thread each: whichever fails last leaves its text
     bool have_grid = false;
     bool maps_stale = false;  // cell updates were applied without rebuilding the derived maps (fxjps_update_cells_deferred)
     int mem_div = 1;          // handles sharing each device (fxjps_set_memory_share): the scratch budgets are divided by it
@@ -214,10 +225,12 @@ int fail(fxjps* h, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (h)
+    if (h) {
+        std::lock_guard<std::mutex> lk(h->err_mu);
         h->err = buf;
-    else
+    } else {
         g_create_error = buf;
+    }
     return code;
 }
 
@@ -307,15 +320,30 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
         const long long nrw = (long long)(rr.l1 - rr.l0 + 1) * (rr.w1 - rr.w0 + 1), ncw = (long long)(rc.l1 - rc.l0 + 1) * (rc.w1 - rc.w0 + 1);
         hipLaunchKernelGGL(fx::k_derive_rows, dim3((unsigned)((nrw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G, d.nb8.p, d.bm.p, rr);
         hipLaunchKernelGGL(fx::k_derive_cols, dim3((unsigned)((ncw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G, d.bm.p, rc);
+        fx::ChangeOut chg{nullptr, nullptr, nullptr, 0u, fx::MapRange{1, 0, 1, 0}};
         if (box) {  // the rows and the columns through the box (a straight jump ends where the line's next stop bit is)
             const fx::MapRange sa{d.bx0, d.bx1, 0, d.PH - 1}, sb{0, d.PW - 1, d.by0, d.by1};
             const long long na = (long long)(sa.l1 - sa.l0 + 1) * d.PH, nb = (long long)d.PW * (sb.w1 - sb.w0 + 1);
-            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa);
-            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sb);
+            // ... and which of those cells changed: where the re-scan of the jump distances starts (k_jd_walk)
+            const bool walk = !(getenv("FXJPS_JD_WALK") && atoi(getenv("FXJPS_JD_WALK")) == 0);  // (0: measurement / test aid -- every record is read)
+            if (walk) {
+                if (!d.chg_ready) {  // (streaming callers only: with the first partial rebuild on a grid)
+                    HIPCHK(h, d.d_chgmap.ensure((size_t)d.PW * d.NS));
+                    HIPCHK(h, d.d_chgcnt.ensure(4));
+                    HIPCHK(h, hipMemsetAsync(d.d_chgmap.p, 0, (size_t)d.PW * d.NS, d.stream));
+                    HIPCHK(h, hipMemsetAsync(d.d_chgcnt.p, 0, 4 * sizeof(unsigned int), d.stream));
+                    d.chg_ready = true;
+                }
+                HIPCHK(h, d.d_chglist.ensure((size_t)(na + nb)));
+                chg = fx::ChangeOut{d.d_chgmap.p, d.d_chglist.p, d.d_chgcnt.p, (uint32_t)(na + nb), fx::MapRange{d.bx0, d.bx1, d.by0, d.by1}};
+            }
+            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa, chg);
+            chg.B = fx::MapRange{1, 0, 1, 0};  // (the box lies in the rows just done)
+            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sb, chg);
         } else {
             const long long ncell = (long long)d.PW * d.PH;
             hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p,
-                               fx::MapRange{0, d.PW - 1, 0, d.PH - 1});
+                               fx::MapRange{0, d.PW - 1, 0, d.PH - 1}, chg);
         }
         {  // the diagonal scan words: a function of the cell infos (and the occupancy) cell by cell -- of the cells above
             const fx::DiagRange dr{box ? 0 : 1, d.bx0, d.bx1, d.by0, d.by1};
@@ -325,7 +353,14 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
                                d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
             // ... and the jump distances: the goal-free jumps themselves, from every cell along every direction, read off
             // the scan words above (after an update: the entries whose old ray passes what the update can have changed)
-            if (box) {
+            if (box && chg.map != nullptr) {
+                // what the update can have changed, found from the changed cells backwards (a walker per changed cell and
+                // direction) instead of by reading every record
+                const int walk_max = getenv("FXJPS_JD_WALK_MAX") ? std::max(1, atoi(getenv("FXJPS_JD_WALK_MAX"))) : FXJPS_JD_WALK_MAX;  // (test aid)
+                const long long nt = (long long)chg.cap * 8, nc = (long long)d.W * d.H;
+                hipLaunchKernelGGL(fx::k_jd_walk, dim3((unsigned)std::min<long long>((nt + 255) / 256, 2048)), dim3(256), 0, d.stream, G, d.jd.p, chg, dr, walk_max);
+                hipLaunchKernelGGL(fx::k_jd_finish, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1024)), dim3(256), 0, d.stream, G, d.jd.p, chg, dr);
+            } else if (box) {
                 const long long nc = (long long)d.W * d.H;
                 hipLaunchKernelGGL(fx::k_update_jd, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, d.stream, G, d.jd.p, dr);
             } else {
@@ -360,6 +395,7 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     d.LINES = std::max(d.PW, d.PH);
     d.WORDS = (std::max(d.PW, d.PH) + 63) / 64;
     d.owner_ready = false;  // (the update lists' owner cells follow the grid's shape)
+    d.chg_ready = false;    // (and so do the marks of the changed cells)
     d.tsh = 0;  // read-set tiles (streaming replan): at most 64 x 64 of them cover the grid
     while (((std::max(W, H) - 1) >> d.tsh) > 63) d.tsh++;
     HIPCHK(h, d.occ.ensure((size_t)W * H));
@@ -380,6 +416,7 @@ uint32_t ceil_log2(uint64_t v) {
 // Gives the memory of pool 0 back (a batch buffer did not fit beside it); the next batch sizes it again from what is free.
 void release_pool0(DevCtx& d) {
     if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
+        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);
     (void)hipStreamSynchronize(d.stream);
     d.tables[0].release();
     d.far[0].release();
@@ -602,6 +639,8 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
         nsolo = 0;
     nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
     if (nsolo != 0u) waves = std::min<uint32_t>(waves, (c.nwaves - nsolo) & ~((uint32_t)fx::WPB - 1u));
+    const bool masked = nsolo != 0u && d.stream_rest != nullptr;  // the head launch on XCDs of its own, the batch's on the others
+    if (masked) waves = std::min<uint32_t>(waves, ((uint32_t)d.n_cu_rest * 4u * (uint32_t)fx::OCC) & ~((uint32_t)fx::WPB - 1u));
     if (pool != 0 || nsolo != 0u || (uint64_t)nrun > (uint64_t)d.n_cu * live_main || d.share * h->mem_div > 1) live_main = 0u;
     // One query per BLOCK (k_search_coop: a searching wavefront and a stager that keeps the LDS tier of its open list in
     // shape, two SIMDs of a CU): for what a handful of long queries decide -- the head launch above, and batches small
@@ -681,7 +720,8 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
             d.solo_target += nsolo / live_solo;
             const auto t0 = std::chrono::steady_clock::now();
             bool late = false;
-            while ((int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
+            // (masked queues: the batch's launch cannot take the head launch's CUs -- nothing to wait for)
+            while (!masked && (int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
                     // (the counter did not arrive in time -- no PCIe atomics, a tool that serialises kernels: after three
                     // such waits in a row this device runs its batches as one launch; fxjps_timing_t::solo_timeouts counts them)
@@ -692,18 +732,27 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
             d.solo_timeouts += late ? 1 : 0;
             d.solo_timeouts_run = late ? d.solo_timeouts_run + 1 : 0;
         }
-        if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, d.stream));
+        hipStream_t bst = d.stream;  // the stream of the batch's launch
+        if (masked) {
+            bst = d.stream_rest;
+            HIPCHK(h, hipStreamWaitEvent(bst, d.ev_solo0, 0));  // (the inputs, queued on d.stream, are in place)
+        }
+        if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, bst));
         if (coop_all) {
             hipLaunchKernelGGL(cfn, dim3(waves), dim3(fx::WAVE * 2), 0, d.stream, A);
         } else if (live_main != 0u) {
             A.solo = live_main;
             hipLaunchKernelGGL(fn, dim3(waves / live_main), block, pad, d.stream, A);
         } else {
-            hipLaunchKernelGGL(fn, dim3(waves / fx::WPB), block, 0, d.stream, A);
+            hipLaunchKernelGGL(fn, dim3(waves / fx::WPB), block, 0, bst, A);
         }
         HIPCHK(h, hipGetLastError());
         if (nsolo != 0u) {
-            HIPCHK(h, hipEventRecord(d.ev_bt1, d.stream));
+            HIPCHK(h, hipEventRecord(d.ev_bt1, bst));
+            if (masked) {
+                HIPCHK(h, hipEventRecord(d.ev_rest1, bst));
+                HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_rest1, 0));
+            }
             HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_solo1, 0));
         }
         if (pool == 0) d.had_solo = nsolo != 0u;
@@ -992,6 +1041,24 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
             h->last_on_host = rc == FXJPS_OK;
         }
     }
+    if (nd > 1 && !rc && !done) {
+        // One host thread per context: each queues its shard's copies and launches, waits for its own search (the head
+        // launch's start counter, then the kernel), packs its paths and brings them back.  The devices never wait for each
+        // other's host-side tail -- run one after the other, eight tails of ~ 23 ms each behind ~ 570 ms of parallel search
+        // capped config 4 at 75 % strong-scaling efficiency by construction.  (The shards share nothing, jps1.py:183-192.)
+        std::vector<int> rcs((size_t)nd, FXJPS_OK);
+        std::vector<std::thread> th;
+        th.reserve((size_t)nd);
+        for (int r = 0; r < nd; r++)
+            th.emplace_back([&, r] {
+                int e = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
+                if (!e) e = finish_shard(h, h->devs[r], hchoice, max_len);
+                rcs[(size_t)r] = e;
+            });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < nd && !rc; r++) rc = rcs[(size_t)r];
+        done = true;
+    }
     for (int r = 0; r < nd && !rc && !done; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
     for (int r = 0; r < nd && !rc && !done; r++) rc = finish_shard(h, h->devs[r], hchoice, max_len);
     if (rc) {
@@ -1120,6 +1187,14 @@ int broadcast_grid(fxjps* h, int W, int H) {
     return FXJPS_OK;
 }
 
+// A handle that fxjps_create_rank made with world > 1 sets its grid with fxjps_set_grid_rank and nothing else: that call
+// is a collective (every rank enters ncclBroadcast), so any other whole-grid setter on such a handle would have this rank
+// wait in a broadcast its peers never join.
+int refuse_on_rank_handle(fxjps* h, const char* what) {
+    if (h->world > 1) return fail(h, FXJPS_E_ARG, "%s on rank %d of %d: a rank handle sets its grid with fxjps_set_grid_rank (collective)", what, h->rank, h->world);
+    return FXJPS_OK;
+}
+
 int finish_set_grid(fxjps* h, int W, int H) {
     int rc = broadcast_grid(h, W, H);
     if (rc) return rc;
@@ -1142,7 +1217,8 @@ void drain_all(fxjps* h) {
     const std::string keep = h->err;
     for (auto& d : h->devs) {
         if (hipSetDevice(d.dev) == hipSuccess) {
-            if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);  // (a head launch may still be running)
+            if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
+        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);  // (a head launch may still be running)
             (void)hipStreamSynchronize(d.stream);
         }
         d.pool_clean[0] = d.pool_clean[1] = false;  // a search may have died half-way through a table
@@ -1155,7 +1231,9 @@ void drain_all(fxjps* h) {
 
 extern "C" {
 
-int fxjps_version(void) { return 300; }
+int fxjps_version(void) { return FXJPS_VERSION; }
+
+int fxjps_timing_size(void) { return (int)sizeof(fxjps_timing_t); }
 
 int fxjps_device_count(void) {
     int n = 0;
@@ -1190,8 +1268,34 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         hipError_t e = hipSetDevice(d.dev);
         if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d.dev);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
-        if (e == hipSuccess) {
+        // (FXJPS_ONE_STREAM=1: measurement aid -- no second stream, hence no head launches, on this handle: how the runtime
+        // deals its hardware queues out over the streams of many handles)
+        const bool one_stream = getenv("FXJPS_ONE_STREAM") && atoi(getenv("FXJPS_ONE_STREAM")) != 0;
+        // FXJPS_HEAD_XCDS=n (1 .. 4; 0 / unset: off): the head launch's stream is made with a CU mask of n XCDs and a third
+        // stream with the complement.  MI355X: 8 XCDs x 32 CUs, each XCD with its own L2; bit i of a queue's CU mask is CU
+        // i / 8 of XCD i % 8 (verified with tools/cumask_probe.hip: HW_REG_XCC_ID of the blocks of masked launches).
+        int head_xcds = 0;
+        if (const char* ev = getenv("FXJPS_HEAD_XCDS")) head_xcds = std::min(4, std::max(0, atoi(ev)));
+        const int ncu = prop.multiProcessorCount;
+        if (e == hipSuccess && !one_stream && head_xcds > 0 && ncu > 0 && ncu % 8 == 0 && ncu <= 1024) {
+            std::vector<uint32_t> mh((size_t)(ncu + 31) / 32, 0u), mr((size_t)(ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; i++) ((i % 8) < head_xcds ? mh : mr)[(size_t)i >> 5] |= 1u << (i & 31);
+            if (hipExtStreamCreateWithCUMask(&d.stream_solo, (uint32_t)mh.size(), mh.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&d.stream_rest, (uint32_t)mr.size(), mr.data()) == hipSuccess &&
+                hipEventCreateWithFlags(&d.ev_rest1, hipEventDisableTiming) == hipSuccess) {
+                d.n_cu_rest = ncu / 8 * (8 - head_xcds);
+            } else {  // (no masked queues here: the plain second stream below)
+                (void)hipGetLastError();
+                if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
+        if (d.stream_rest) (void)hipStreamDestroy(d.stream_rest);
+        if (d.ev_rest1) (void)hipEventDestroy(d.ev_rest1);
+                if (d.stream_rest) (void)hipStreamDestroy(d.stream_rest);
+                d.stream_solo = d.stream_rest = nullptr;
+                d.n_cu_rest = 0;
+            }
+        }
+        if (e == hipSuccess && !one_stream && !d.stream_solo) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
+        if (e == hipSuccess && !one_stream) {
             // (fine-grained, mapped: the kernel counts with a system-scope atomic, the host polls)
             if (hipHostMalloc((void**)&d.solo_started, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
                 *d.solo_started = 0u;
@@ -1248,6 +1352,41 @@ int fxjps_rank_unique_id(void* out_id128) {
     if (get(&id) != 0) return fail(nullptr, FXJPS_E_COMM, "ncclGetUniqueId failed");
     memcpy(out_id128, &id, sizeof(id));
     return FXJPS_OK;  // (the library stays loaded: the handle made next uses it)
+}
+
+int fxjps_rank_preflight(int device) {
+    int navail = 0;
+    if (hipGetDeviceCount(&navail) != hipSuccess || navail <= 0) return fail(nullptr, FXJPS_E_NODEV, "no HIP device visible");
+    if (device < 0 || device >= navail) return fail(nullptr, FXJPS_E_ARG, "device id %d but %d device(s) visible", device, navail);
+    void* probe = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc(&probe, 256);
+    if (e == hipSuccess) e = hipFree(probe);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, FXJPS_E_HIP, "device %d: %s", device, hipGetErrorString(e));
+    }
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(nullptr, FXJPS_E_COMM, "cannot load librccl.so: %s", dlerror());
+    for (const char* sym : {"ncclGetUniqueId", "ncclCommInitRank", "ncclBroadcast", "ncclCommDestroy"})
+        if (!dlsym(lib, sym)) return fail(nullptr, FXJPS_E_COMM, "%s not found in librccl.so", sym);
+    return FXJPS_OK;  // (the library stays loaded: the handle made next uses it)
+}
+
+int fxjps_reserve_grid(fxjps_t* h, int32_t W, int32_t H) {
+    if (!h) return FXJPS_E_ARG;
+    if (W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
+    h->have_grid = false;  // (the buffers of the resident grid may have been replaced)
+    h->q_results_valid = false;
+    for (auto& d : h->devs) {
+        int rc = alloc_grid(h, d, W, H);
+        if (rc) return rc;
+        d.pool_clean[0] = d.pool_clean[1] = false;
+        d.cfg[0] = ScratchCfg();
+        d.cfg[1] = ScratchCfg();
+    }
+    return FXJPS_OK;
 }
 
 int fxjps_create_rank(int device, int rank, int world, const void* id128, fxjps_t** out) {
@@ -1312,6 +1451,7 @@ void fxjps_destroy(fxjps_t* h) {
         if (d.dev < 0) continue;
         (void)hipSetDevice(d.dev);
         if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
+        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         d.occ.release();
         d.comp.release();
@@ -1351,6 +1491,9 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_upd_val.release();
         d.d_upd_chg.release();
         d.d_owner.release();
+        d.d_chgmap.release();
+        d.d_chglist.release();
+        d.d_chgcnt.release();
         d.h_len.release();
         d.h_cells.release();
         d.h_cost.release();
@@ -1364,6 +1507,8 @@ void fxjps_destroy(fxjps_t* h) {
         if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
         if (d.ev_solo1) (void)hipEventDestroy(d.ev_solo1);
         if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
+        if (d.stream_rest) (void)hipStreamDestroy(d.stream_rest);
+        if (d.ev_rest1) (void)hipEventDestroy(d.ev_rest1);
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);
         for (hipEvent_t ev : {d.ev_hd0, d.ev_hd1, d.ev_bt0, d.ev_bt1})
@@ -1378,6 +1523,7 @@ const char* fxjps_last_error(fxjps_t* h) { return h ? h->err.c_str() : g_create_
 int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
     if (!h) return FXJPS_E_ARG;
     if (!occ || W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
+    if (int rr = refuse_on_rank_handle(h, "fxjps_set_grid")) return rr;
     h->have_grid = false;
     h->q_results_valid = false;
     for (auto& d : h->devs) {
@@ -1397,6 +1543,7 @@ int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
 int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
     if (!h) return FXJPS_E_ARG;
     if (!d_occ || W < 1 || H < 1 || W > 8190 || H > 8190) return fail(h, FXJPS_E_ARG, "grid must be 1..8190 cells a side");
+    if (int rr = refuse_on_rank_handle(h, "fxjps_set_grid_device")) return rr;
     h->have_grid = false;
     h->q_results_valid = false;
     for (auto& d : h->devs) {
@@ -1419,6 +1566,7 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
     if (!h) return FXJPS_E_ARG;
     if (!raw || !start_xy || !goal_xy || W0 < 1 || H0 < 1 || ifa < 0 || ifa > 64 || (variant != 0 && variant != 1))
         return fail(h, FXJPS_E_ARG, "bad prepare_grid arguments");
+    if (int rr = refuse_on_rank_handle(h, "fxjps_prepare_grid")) return rr;
     const long long sx = start_xy[0], sy = start_xy[1], gx = goal_xy[0], gy = goal_xy[1];
     // global_planner_st.py:230-235 / global_planner_ccst.py:415-420
     long long o2x = -2ll * ifa, o2y = -2ll * ifa;
@@ -1572,6 +1720,7 @@ int fxjps_publish_map(fxjps_t* h, int8_t* out_data, int32_t* out_width, int32_t*
 int fxjps_set_grid_image(fxjps_t* h, const uint8_t* gray, int32_t rows, int32_t cols) {
     if (!h) return FXJPS_E_ARG;
     if (!gray || rows < 1 || cols < 1 || rows > 8190 || cols > 8190) return fail(h, FXJPS_E_ARG, "image must be 1..8190 pixels a side");
+    if (int rr = refuse_on_rank_handle(h, "fxjps_set_grid_image")) return rr;
     h->have_grid = false;
     h->q_results_valid = false;
     const size_t n = (size_t)rows * cols;
@@ -1720,21 +1869,29 @@ int emit_csr(fxjps_t* h, int64_t nq, int64_t* out_offsets, int32_t* out_cells_xy
              double* out_cost) {
     int64_t base = 0;
     bool fits = true;
+    // every context's slice of the caller's arrays: where it starts is a prefix sum over the shards' totals, the copies
+    // themselves are independent -- one host thread per context when there are several
+    std::vector<std::thread> th;
+    const bool par = h->devs.size() > 1;
     for (auto& d : h->devs) {
         if (d.nq == 0) continue;
-        memcpy(out_len + d.q0, d.h_len.p, (size_t)d.nq * sizeof(int32_t));
-        memcpy(out_cost + d.q0, d.h_cost.p, (size_t)d.nq * sizeof(double));
-        for (int64_t i = 0; i < d.nq; i++) out_offsets[d.q0 + i] = base + d.h_offsets.p[i];
         const int64_t total = d.h_offsets.p[d.nq];
-        if (!out_cells_xy) {
-            // sizing call: the cells stay in the handle for fxjps_last_cells()
-        } else if (base + total > cells_capacity) {
-            fits = false;
-        } else if (total > 0) {
-            host_copy(out_cells_xy + 2 * base, d.h_cells.p, (size_t)total * 2 * sizeof(int32_t));
-        }
+        const bool cells = out_cells_xy && base + total <= cells_capacity && total > 0;
+        if (out_cells_xy && base + total > cells_capacity) fits = false;  // (out_cells_xy == NULL: sizing call, the cells stay in the handle for fxjps_last_cells())
+        DevCtx* dp = &d;
+        const auto put = [=] {
+            memcpy(out_len + dp->q0, dp->h_len.p, (size_t)dp->nq * sizeof(int32_t));
+            memcpy(out_cost + dp->q0, dp->h_cost.p, (size_t)dp->nq * sizeof(double));
+            for (int64_t i = 0; i < dp->nq; i++) out_offsets[dp->q0 + i] = base + dp->h_offsets.p[i];
+            if (cells) host_copy(out_cells_xy + 2 * base, dp->h_cells.p, (size_t)total * 2 * sizeof(int32_t));
+        };
+        if (par)
+            th.emplace_back(put);
+        else
+            put();
         base += total;
     }
+    for (auto& t : th) t.join();
     if (out_offsets) out_offsets[nq] = base;
     h->last_nq = nq;
     if (!fits) return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, batch needs %lld", (long long)cells_capacity, (long long)base);
@@ -1866,12 +2023,27 @@ int fxjps_last_cells(fxjps_t* h, int32_t* out_cells_xy, int64_t cells_capacity) 
     int64_t base = 0;
     for (auto& d : h->devs) {
         if (d.nq == 0 || !d.h_offsets.p) continue;
+        base += d.h_offsets.p[d.nq];
+    }
+    if (base > cells_capacity)
+        return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, the last batch has more", (long long)cells_capacity);
+    base = 0;
+    std::vector<std::thread> th;  // (several contexts: their slices are copied side by side, as in emit_csr)
+    const bool par = h->devs.size() > 1;
+    for (auto& d : h->devs) {
+        if (d.nq == 0 || !d.h_offsets.p) continue;
         const int64_t total = d.h_offsets.p[d.nq];
-        if (base + total > cells_capacity)
-            return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, the last batch has more", (long long)cells_capacity);
-        if (total > 0) host_copy(out_cells_xy + 2 * base, d.h_cells.p, (size_t)total * 2 * sizeof(int32_t));
+        if (total > 0) {
+            int32_t* dst = out_cells_xy + 2 * base;
+            const int32_t* src = d.h_cells.p;
+            if (par)
+                th.emplace_back([=] { host_copy(dst, src, (size_t)total * 2 * sizeof(int32_t)); });
+            else
+                host_copy(dst, src, (size_t)total * 2 * sizeof(int32_t));
+        }
         base += total;
     }
+    for (auto& t : th) t.join();
     return FXJPS_OK;
 }
 
@@ -1909,6 +2081,7 @@ int fxjps_set_memory_share(fxjps_t* h, int32_t handles_per_device) {
                                    // a pool sized for the whole device would stay, and be credited to this handle's budget
             if (hipSetDevice(d.dev) == hipSuccess) {
                 if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
+        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);
                 (void)hipStreamSynchronize(d.stream);
             }
             for (int p = 0; p < 2; p++) {
@@ -2133,6 +2306,12 @@ int fxjps_waypoint_st_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, cons
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out) {
     if (!h || !out) return FXJPS_E_ARG;
     *out = h->timing;
+    return FXJPS_OK;
+}
+
+int fxjps_last_timing_sized(fxjps_t* h, void* out, int64_t out_size) {
+    if (!h || !out || out_size < 0) return FXJPS_E_ARG;
+    memcpy(out, &h->timing, (size_t)std::min<int64_t>(out_size, (int64_t)sizeof(fxjps_timing_t)));
     return FXJPS_OK;
 }
 

@@ -69,6 +69,21 @@ class Planner(object):
             raise FxjpsError(rc, (L.fxjps_last_error(None) or b"").decode())
         return buf.raw
 
+    @staticmethod
+    def rank_preflight(device):
+        """What can keep THIS process out of the ranks' collectives, checked without one: the device exists and takes an
+        allocation, librccl loads and has the entry points used.  -> None, or the reason as text."""
+        try:
+            L = _lib.load()
+            rc = L.fxjps_rank_preflight(int(device))
+        except (OSError, FxjpsError) as e:
+            return str(e)
+        return None if rc == 0 else "fxjps error %d: %s" % (rc, (L.fxjps_last_error(None) or b"").decode())
+
+    def reserve_grid(self, W, H):
+        """Allocate the device buffers of a W x H grid (what the next set_grid* call would allocate), nothing else."""
+        self._chk(self._L.fxjps_reserve_grid(self._h, int(W), int(H)))
+
     def set_grid_rank(self, occ, W, H):
         """Collective over the ranks of `for_rank`: rank 0 passes the uint8 [W][H] occupancy, the others None; ONE
         ncclBroadcast of the W*H bytes inside the library, then every rank builds its maps."""

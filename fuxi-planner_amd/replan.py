@@ -10,10 +10,49 @@ vehicle whose last search happened at x == 0.0 exactly always searches again (ke
         path1 = jps1.method(mapu, tuple(map_start), tuple(map_goal), 2)
         throttle.mark(planner.parse_local_position(planner.pos))      # the position is read again after the search
 """
+import os
+import sys
 import time
+import warnings
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+
+HW_QUEUES = 16  # hardware queues the pipelines below want the HIP runtime to hand out (its default is 4)
+
+
+def configure_hw_queues(n=HW_QUEUES):
+    """Frames / batches in flight need hardware queues: the HIP runtime maps every stream onto one of GPU_MAX_HW_QUEUES
+    (default 4) queues, and the persistent search kernels of two handles whose streams share a queue run one after the
+    other.  The variable is read ONCE, when the runtime initialises in this process -- so it has to be in the environment
+    before the first GPU call (of this package or of anything else, torch included).  Call this first thing in a process
+    that will build a `FramePipeline` / `BatchPipeline`; the pipelines call it themselves and warn when it is too late.
+    -> the number of queues the runtime will use (or is assumed to use), None when that cannot be arranged any more."""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        try:
+            return int(cur)
+        except ValueError:
+            return None
+    from . import _lib
+    torch = sys.modules.get("torch")
+    hip_up = _lib._lib is not None or (torch is not None and getattr(getattr(torch, "cuda", None), "is_initialized", lambda: False)())
+    if hip_up:
+        return None
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return int(n)
+
+
+def _want_queues(k, what):
+    got = configure_hw_queues()
+    if got is None:
+        warnings.warn("%s with %d planner handles: the HIP runtime of this process was initialised without GPU_MAX_HW_QUEUES "
+                      "(4 hardware queues): handles that share a queue plan one after the other.  Call "
+                      "fuxi_planner_amd.replan.configure_hw_queues() before the first GPU call, or set GPU_MAX_HW_QUEUES=%d in "
+                      "the environment." % (what, k, HW_QUEUES), RuntimeWarning, stacklevel=3)
+    elif got < k:
+        warnings.warn("%s with %d planner handles on %d hardware queues (GPU_MAX_HW_QUEUES): handles that share a queue plan "
+                      "one after the other" % (what, k, got), RuntimeWarning, stacklevel=3)
 
 
 class ReplanThrottle(object):
@@ -55,6 +94,7 @@ class FramePipeline(object):
     def __init__(self, device, k, occ, starts, goals, hchoice=2, max_path_len=None):
         from .planner import Planner
         self.k = int(k)
+        _want_queues(self.k, "FramePipeline")
         self.planners = [Planner([device]) for _ in range(self.k)]
         for p in self.planners:
             p.set_memory_share(self.k)  # K handles on one device: each sizes its scratch for a K-th of it
@@ -131,6 +171,7 @@ class BatchPipeline(object):
     def __init__(self, device, k, occ):
         from .planner import Planner
         self.k = int(k)
+        _want_queues(self.k, "BatchPipeline")
         self.planners = [Planner([device]) for _ in range(self.k)]
         for p in self.planners:
             p.set_memory_share(self.k)

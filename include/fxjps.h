@@ -59,6 +59,14 @@ typedef struct fxjps fxjps_t;
  * in the repository is the test oracle under oracle/, which the library never links or loads). */
 #define FXJPS_BACKEND_HIP 1
 
+/* Version of this header: fxjps_version() of the loaded library must equal it.  History of what a C host has to know:
+ *   300  round 3
+ *   300  (round 4, NOT bumped -- a mistake) fxjps_timing_t grew by head_launch_ms, batch_launch_ms, solo_timeouts
+ *   500  round 5: the version says so now; fxjps_timing_size() / fxjps_last_timing_sized() for hosts that want to be safe
+ *        against the next growth; the whole-grid setters refuse handles of fxjps_create_rank with world > 1;
+ *        fxjps_rank_preflight, fxjps_reserve_grid.
+ * fxjps_timing_t only ever grows at its end. */
+#define FXJPS_VERSION 500
 int fxjps_version(void);
 
 /* Number of HIP devices visible, or a negative code. */
@@ -81,6 +89,15 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out);
 int fxjps_rank_unique_id(void* out_id128);
 int fxjps_create_rank(int device, int rank, int world, const void* id128, fxjps_t** out);
 int fxjps_set_grid_rank(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H);
+/* fxjps_create_rank (ncclCommInitRank) and fxjps_set_grid_rank (ncclBroadcast) are COLLECTIVES: a rank that fails before
+ * it joins one leaves the others waiting inside RCCL.  What can fail on ONE rank is therefore checked first, without any
+ * collective, and the ranks agree on the outcome over their own channel before anybody enters (fuxi_planner_amd.ranks does):
+ * fxjps_rank_preflight -- the device exists and takes an allocation, librccl loads and has the four entry points used;
+ * fxjps_reserve_grid   -- the handle's buffers for a W x H grid are allocated (what fxjps_set_grid_rank would allocate).
+ * On a handle of fxjps_create_rank with world > 1 every OTHER whole-grid setter (fxjps_set_grid, _device, _image,
+ * fxjps_prepare_*) returns FXJPS_E_ARG: it would enter a broadcast alone. */
+int fxjps_rank_preflight(int device);
+int fxjps_reserve_grid(fxjps_t* h, int32_t W, int32_t H);
 
 void fxjps_destroy(fxjps_t* h);
 
@@ -222,7 +239,12 @@ typedef struct fxjps_timing {
                                 since the handle was created (3 in a row on a device: it runs its batches as one launch from
                                 then on; a lone one is the cold first launch of a kernel) */
 } fxjps_timing_t;
+/* fxjps_last_timing writes sizeof(fxjps_timing_t) bytes AS THE LIBRARY WAS BUILT: a host compiled against an older header
+ * checks fxjps_version() == FXJPS_VERSION (or fxjps_timing_size() == sizeof(fxjps_timing_t)) first, or calls
+ * fxjps_last_timing_sized, which writes at most out_size bytes (the struct only grows at its end). */
 int fxjps_last_timing(fxjps_t* h, fxjps_timing_t* out);
+int fxjps_timing_size(void);
+int fxjps_last_timing_sized(fxjps_t* h, void* out, int64_t out_size);
 
 /* Per-context figures of the last batch (ctx = 0 .. contexts-1, the order of device_ids at fxjps_create): the device
  * it ran on, the queries of its contiguous shard, the HIP-event time of its search kernel launches, its resident

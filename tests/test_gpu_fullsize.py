@@ -106,12 +106,21 @@ def test_config4_full_1m_in_eight_shards(planner, oracle):
     s, g = synth.synth_queries(occ, 1, nq)
     planner.set_grid_occ(occ)
     one = planner.plan_batch(s, g, 2, 1024)
-    assert (one[3] >= 0).all() and planner.timing()["retried"] == 0
+    tm1 = planner.timing()
+    assert (one[3] >= 0).all() and tm1["retried"] == 0
     with fx.Planner([0] * 8) as p8:
         p8.set_grid_occ(occ)
         assert p8.comm_info() == {"contexts": 8, "devices": 1, "rccl_ranks": 0}
         res = p8.plan_batch(s, g, 2, 1024)
+        res = p8.plan_batch(s, g, 2, 1024)  # (warm: the first call allocates the eight contexts' buffers)
+        tm8 = p8.timing()
         per = p8.timing_per_context()
+        # The host side of the shards runs on a thread per context: what a batch costs beyond its search kernels (the
+        # waits, the length scan, the gather, the copies back) must not add up over the contexts.  (Run one after the
+        # other, eight such tails would cap config 4 at 75 %% strong-scaling efficiency by construction.)
+        tail1, tail8 = tm1["total_ms"] - tm1["search_kernel_ms"], tm8["total_ms"] - tm8["search_kernel_ms"]
+        print("config 4 host-side tail: one context %.1f ms, eight contexts %.1f ms (total %.1f / %.1f ms)" % (tail1, tail8, tm1["total_ms"], tm8["total_ms"]))
+        assert tail8 <= 1.3 * tail1 + 15.0, (tail1, tail8)
         assert [c["queries"] for c in per] == [shard_bounds(nq, r, 8)[1] - shard_bounds(nq, r, 8)[0] for r in range(8)]
         assert all(c["kernel_ms"] > 0 and c["waves"] > 0 for c in per) and p8.timing()["retried"] == 0
         print("config 4, eight contexts on one GPU: kernel ms per shard", [round(c["kernel_ms"], 1) for c in per])
@@ -533,6 +542,66 @@ def test_frames_in_flight_config5_eight_handles(oracle):
         futs = [pipe.submit(xy, val) for xy, val, _ in frames]
         for fr, f in enumerate(futs):
             assert_same(f.result(), oracle_csr(oracle, frames[fr][2], s, g, wl["hchoice"], wl["max_path_len"]))
+
+
+_PIPE_AS_BENCH = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from fuxi_planner_amd import replan, synth
+assert replan.configure_hw_queues() == 16 and os.environ["GPU_MAX_HW_QUEUES"] == "16"   # nothing has touched the GPU yet
+from fuxi_planner_amd.replan import BatchPipeline, FramePipeline
+from oracle import oracle
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from test_gpu_fullsize import assert_same, oracle_csr
+with open(os.path.join(%(root)r, "fuxi-planner_amd", "workloads.json")) as f:
+    WL = json.load(f)
+mode = sys.argv[1]
+if mode == "c5pipe":
+    wl = WL["c5pipe"]
+    K = int(wl["frames_in_flight"])
+    occ = synth.synth_grid(wl["W"], wl["H"], wl["grid_seed"], wl["p"])
+    s, g = synth.synth_queries(occ, wl["qseed"], wl["nq"])
+    keep = np.zeros(occ.shape, dtype=bool)
+    keep[s[:, 0], s[:, 1]] = True
+    keep[g[:, 0], g[:, 1]] = True
+    grid = occ.copy()
+    frames = []
+    for fr in range(4 * K):
+        xy, val = synth.frame_update(grid, keep, fr, wl)
+        synth.apply_toggles(grid, xy, val)
+        frames.append((xy, val, grid.copy()))
+    with FramePipeline(0, K, occ, s, g, wl["hchoice"], wl["max_path_len"]) as pipe:
+        futs = [pipe.submit(xy, val) for xy, val, _ in frames]
+        for fr, f in enumerate(futs):
+            assert_same(f.result(), oracle_csr(oracle, frames[fr][2], s, g, wl["hchoice"], wl["max_path_len"]))
+    print("PIPE-OK c5pipe handles=%%d frames=%%d" %% (K, len(frames)))
+else:
+    wl = WL["c2"]
+    occ = synth.synth_grid(wl["W"], wl["H"], wl["grid_seed"], wl["p"])
+    s, g = synth.synth_queries(occ, wl["qseed"], 3 * wl["nq"])
+    nq = wl["nq"]
+    with BatchPipeline(0, 2, occ) as pipe:
+        # the headline's own batch first, then the next two of the same stream (BASELINE config 4's queries 10 000 .. 29 999)
+        futs = [pipe.submit(s[b * nq:(b + 1) * nq], g[b * nq:(b + 1) * nq], wl["hchoice"], wl["max_path_len"]) for b in range(3)]
+        for b, f in enumerate(futs):
+            assert_same(f.result(), oracle_csr(oracle, occ, s[b * nq:(b + 1) * nq], g[b * nq:(b + 1) * nq], wl["hchoice"], wl["max_path_len"]))
+    print("PIPE-OK c2pipe handles=2 batches=3 x %%d" %% nq)
+"""
+
+
+@pytest.mark.parametrize("mode", ["c5pipe", "c2pipe"])
+def test_pipelines_the_way_bench_runs_them(mode, tmp_path, oracle):
+    """What the driver's default line runs as config.also.c5pipe / c2pipe, against the oracle, in a process of its own so
+    that GPU_MAX_HW_QUEUES = 16 is in place before the HIP runtime starts (fuxi_planner_amd.replan.configure_hw_queues):
+    c5pipe -- BASELINE config 5 through the workload's own number of planner handles (12), four turns each, every path of
+    every frame on that frame's grid; c2pipe -- TWO handles, three 10 000-query config-2 batches (memory share 2: no head
+    launch), every path."""
+    script = tmp_path / "pipe_as_bench.py"
+    script.write_text(_PIPE_AS_BENCH % {"root": ROOT})
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, str(script), mode], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "PIPE-OK " + mode in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_grid_of_6144_with_2_to_the_27_slot_tables(planner, oracle):

@@ -242,3 +242,114 @@ def test_rendezvous_passes_over_a_taken_port():
     foreign.close()
     assert sorted(out) == [0, 1, 2]
     assert all(v == (base + 6, "token", [2.0]) for v in out.values()), out
+
+
+def test_rendezvous_wire_format_builds_nothing_but_data():
+    """The frames of fuxi_planner_amd.ranks carry a small tagged encoding, never a pickle: what the ranks exchange comes
+    back bit for bit, anything else is refused -- when sending and when receiving."""
+    import pickle
+    from fuxi_planner_amd import ranks
+    msg = [None, True, False, 3, -(1 << 40), 0.1 + 0.2, float("inf"), "grid", b"\x00\xff", (1, [2.5, "x"]),
+           np.arange(12, dtype=np.int32).reshape(3, 2, 2), np.zeros((0, 2), np.int32), np.array([1.5, -0.0]), np.float64(7.25), np.int64(9)]
+    out = []
+    ranks._enc(msg, out)
+    wire = b"".join(out)
+    back, at = ranks._dec(memoryview(wire), 0)
+    assert at == len(wire)
+    assert back[:10] == msg[:10] and struct_bytes(back[5]) == struct_bytes(msg[5])
+    assert np.array_equal(back[10], msg[10]) and back[10].dtype == np.int32 and back[11].shape == (0, 2)
+    assert back[12].tobytes() == msg[12].tobytes() and back[13] == 7.25 and back[14] == 9
+    for bad in (object(), {"a": 1}, {1}, np.array(["s"]), np.array([object()], dtype=object)):
+        with pytest.raises(TypeError):
+            ranks._enc(bad, [])
+    for junk in (pickle.dumps((1, 2)), b"Z", b"a\x06object\x00", b"l" + (1 << 40).to_bytes(8, "little"), b"s" + (99).to_bytes(8, "little") + b"x"):
+        with pytest.raises((ValueError, Exception)) as e:
+            ranks._dec(memoryview(junk), 0)
+        assert not isinstance(e.value, (AttributeError, ImportError))
+    # a frame whose tag does not verify is dropped before its payload is looked at
+    import socket
+    a, b = socket.socketpair()
+    key, other = ranks.run_key("127.0.0.1", 1, 2, "run-A"), ranks.run_key("127.0.0.1", 1, 2, "run-B")
+    assert key != other and key != ranks.run_key("127.0.0.1", 2, 2, "run-A") and key != ranks.run_key("127.0.0.1", 1, 3, "run-A")
+    ranks._send_frame(a, other, ranks._K_DATA, wire)
+    with pytest.raises(ValueError, match="not authenticated"):
+        ranks._recv_frame(b, key, ranks._K_DATA, None)
+    ranks._send_frame(a, key, ranks._K_DATA, wire)
+    assert ranks._recv_frame(b, key, ranks._K_DATA, None) == wire
+    a.close()
+    b.close()
+
+
+def struct_bytes(x):
+    import struct
+    return struct.pack("<d", x)
+
+
+def test_rendezvous_keeps_runs_apart():
+    """Two runs whose ports collide (same address, same port, same world size) do not talk to each other: rank 0 of run A
+    drops the greeting of run B's rank (it is not authenticated with A's key) and goes on waiting for its own."""
+    import threading
+    from fuxi_planner_amd.ranks import Rendezvous
+    base = 29911
+    out, errs = {}, {}
+
+    def rank(name, r, token, timeout):
+        try:
+            rdv = Rendezvous(r, 2, "127.0.0.1", base, timeout=timeout, token=token, grace=0.5)
+            out[name] = rdv.bcast(token if r == 0 else None)
+            rdv.barrier()
+            rdv.close()
+        except Exception as e:  # noqa: BLE001
+            errs[name] = e
+
+    a0 = threading.Thread(target=rank, args=("a0", 0, "run-A", 60.0))
+    b1 = threading.Thread(target=rank, args=("b1", 1, "run-B", 4.0))  # a rank of ANOTHER run: finds nobody
+    a0.start()
+    b1.start()
+    b1.join(timeout=60)
+    assert isinstance(errs.get("b1"), TimeoutError) and "b1" not in out, (out, errs)
+    a1 = threading.Thread(target=rank, args=("a1", 1, "run-A", 60.0))
+    a1.start()
+    a0.join(timeout=60)
+    a1.join(timeout=60)
+    assert out == {"a0": "run-A", "a1": "run-A"} and list(errs) == ["b1"], (out, errs)
+
+
+def test_rendezvous_times_out_on_a_silent_peer():
+    """A peer that dies after the star is built ends the run with an error, not with a hang: every socket keeps a finite
+    timeout."""
+    import threading
+    from fuxi_planner_amd.ranks import Rendezvous
+    base = 29931
+    res = {}
+
+    def rank0():
+        rdv = Rendezvous(0, 2, "127.0.0.1", base, timeout=30.0, io_timeout=1.0)
+        try:
+            rdv.gather("x")  # rank 1 never sends
+        except TimeoutError as e:
+            res["err"] = e
+        rdv.close()
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    r1 = Rendezvous(1, 2, "127.0.0.1", base, timeout=30.0)
+    t.join(timeout=30)
+    r1.close()
+    assert isinstance(res.get("err"), TimeoutError)
+
+
+def test_hw_queue_setting_is_made_before_the_runtime_starts(monkeypatch):
+    """fuxi_planner_amd.replan.configure_hw_queues: sets GPU_MAX_HW_QUEUES while nothing has touched the GPU, leaves a
+    value the caller chose alone, and says None (the pipelines then warn) once the library is loaded without it."""
+    from fuxi_planner_amd import _lib, replan
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "24")
+    assert replan.configure_hw_queues() == 24
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert replan.configure_hw_queues() == 16 and os.environ["GPU_MAX_HW_QUEUES"] == "16"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setattr(_lib, "_lib", object())
+    assert replan.configure_hw_queues() is None and "GPU_MAX_HW_QUEUES" not in os.environ
+    with pytest.warns(RuntimeWarning, match="hardware queues"):
+        replan._want_queues(12, "FramePipeline")

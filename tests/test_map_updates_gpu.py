@@ -35,13 +35,22 @@ def check_against_fresh(p, q, cur, tag):
     return len(np.unique(ra)), len(np.unique(rb))
 
 
-def test_partial_rebuild_equals_fresh_upload(oracle):
+@pytest.mark.parametrize("jd_mode", ["walk", "walk_max_3", "stream"])
+def test_partial_rebuild_equals_fresh_upload(oracle, jd_mode, monkeypatch):
+    """jd_mode: how the jump distances follow an update -- from the changed cells backwards (k_jd_walk; on the open maps
+    below walks outgrow their bound and the records are streamed after all), the same with walks of at most 3 steps (the
+    hand-over to the streaming form on every map), every record read (round 4's k_update_jd)."""
     import fuxi_planner_amd as fx
     from fuxi_planner_amd import synth
     from test_gpu_parity import gpu_vs_oracle
+    if jd_mode == "walk_max_3":
+        monkeypatch.setenv("FXJPS_JD_WALK_MAX", "3")
+    elif jd_mode == "stream":
+        monkeypatch.setenv("FXJPS_JD_WALK", "0")
     rng = np.random.default_rng(77)
+    shapes = ((1024, 1024, 0.20), (700, 333, 0.3), (130, 2100, 0.15), (65, 64, 0.4), (600, 500, 0.0), (333, 800, 0.01), (512, 512, 0.04))
     with fx.Planner([0]) as p, fx.Planner([0]) as q:
-        for (W, H, dens) in ((1024, 1024, 0.20), (700, 333, 0.3), (130, 2100, 0.15), (65, 64, 0.4)):
+        for (W, H, dens) in (shapes if jd_mode == "walk" else shapes[1:6]):
             cur = (rng.random((W, H)) < dens).astype(np.uint8)
             p.set_grid_occ(cur)
             s, g = synth.synth_queries(cur, 3, 300)

@@ -1,0 +1,58 @@
+#!/bin/bash
+# One GPU-box session of round 5 (run through gpurun).  Usage: tools/gpu_round5.sh <tag> [steps...]
+#   every step of tools/gpu_round4.sh (tests quick bench lines one profiles busy multi stress), plus:
+#   cumask     tools/cumask_probe: where the blocks of CU-masked launches land (XCD / CU)
+#   headxcd    A/B of FXJPS_HEAD_XCDS x FXJPS_SOLO on config 2 (FX_HEAD="<xcds>:<solo> ...")
+#   queues     c5pipe under rocprofv3 --kernel-trace for "<queues>:<K>[:one]" settings (FX_QK), tools/queue_map.py on each
+#   window     the 64 x 64 window update at 4096^2, walk / stream (tests/test_map_updates_gpu.py prints it)
+# Every step checks its logs for a GPU fault before the next program is started.
+: ${GRAFT_REPO_ROOT:?must run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
+TAG=${1:-r5}; shift
+STEPS=${@:-tests bench}
+OUT=gpurun_out/$TAG
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" || exit 9
+mkdir -p $OUT
+chk() { if grep -q "Memory access fault\|HSA_STATUS_ERROR\|GPU coredump\|Aborted (core dumped)" "$@" 2>/dev/null; then echo "GPU FAULT reported in $*: stopping"; exit 3; fi; }
+for s in $STEPS; do
+case $s in
+cumask)
+  timeout -k 10 120 tools/cumask_probe > $OUT/cumask.txt 2>&1; echo "cumask rc=$?"; cat $OUT/cumask.txt; chk $OUT/cumask.txt;;
+headxcd)
+  for hs in ${FX_HEAD:-0:16 1:16 1:32 2:32 2:48}; do
+    x=${hs%%:*}; n=${hs##*:}
+    FXJPS_HEAD_XCDS=$x FXJPS_SOLO=$n timeout -k 10 300 python bench.py --workload ${FX_HEAD_WL:-c2} --steps ${FX_STEPS:-8} --warmup 3 --no-also --no-cpu-baseline > $OUT/head_${x}_$n.json 2> $OUT/head_${x}_$n.err; rc=$?
+    chk $OUT/head_${x}_$n.err
+    python3 - $OUT/head_${x}_$n.json $x $n $rc <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("head xcds %s solo %s: %.1f k plans/s, %.2f ms/step, kernel %.2f ms, launches %s" % (sys.argv[2], sys.argv[3], d["value"] / 1e3, d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["launch_ms"]))
+except Exception as e:
+    print("head xcds %s solo %s: rc %s, no line (%r)" % (sys.argv[2], sys.argv[3], sys.argv[4], e))
+PY
+  done;;
+queues)
+  for qk in ${FX_QK:-16:12 16:16}; do
+    IFS=: read q k one <<< "$qk"
+    P=$OUT/queues_${q}_${k}${one:+_one}; rm -rf $P
+    GPU_MAX_HW_QUEUES=$q FXJPS_ONE_STREAM=${one:+1} timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $P -- python3 bench.py --workload c5pipe --steps ${FX_QSTEPS:-240} --warmup 24 --frames-in-flight $k --no-also --no-cpu-baseline > $P.json 2> $P.err
+    chk $P.err
+    python3 - $P.json $q $k "$one" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]); c = d["config"]
+    print("queues", sys.argv[2], "K", sys.argv[3], sys.argv[4], ":", round(c["frames_per_s"], 1), "frames/s (under the tracer)", {a: round(b, 1) for a, b in c["submit_to_paths_latency_ms"].items()})
+except Exception as e:
+    print("no line", repr(e))
+PY
+    python3 tools/queue_map.py $P > $P.map.txt 2>&1; cat $P.map.txt
+    rm -rf $P  # (the traces are large; the map is what is kept)
+  done;;
+window)
+  timeout -k 10 600 python -m pytest tests/test_map_updates_gpu.py -m gpu -q -s -x -k "window" > $OUT/window.log 2>&1; grep "window update\|passed\|failed" $OUT/window.log
+  FXJPS_JD_WALK=0 timeout -k 10 600 python -m pytest tests/test_map_updates_gpu.py -m gpu -q -s -x -k "window" > $OUT/window_stream.log 2>&1; grep "window update\|passed\|failed" $OUT/window_stream.log
+  chk $OUT/window.log $OUT/window_stream.log;;
+*)
+  tools/gpu_round4.sh $TAG $s || exit $?;;
+esac
+done
