@@ -108,15 +108,12 @@ struct DevCtx {
     size_t mem_total = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_solo = nullptr;  // the launch of the longest queries, one wavefront per CU, beside the batch's launch
-    hipStream_t stream_rest = nullptr;  // FXJPS_HEAD_XCDS=n: stream_solo may only use the CUs of n XCDs (an L2 of their own), and the
-                                        // batch's launch, while a head launch runs beside it, goes to this stream, which may only use the others
-    int n_cu_rest = 0;                  // ... and how many those are
-    hipEvent_t ev_rest1 = nullptr;
     uint32_t* solo_started = nullptr;   // pinned host word: blocks of such launches that have started (only ever counts up)
     uint32_t solo_target = 0;           // ... and how many have been launched
     int solo_timeouts = 0;              // waits for that counter that ran into their 5 ms bound, since the handle was created
     int solo_timeouts_run = 0;          // ... in a row (3: no more head launches on this device; a cold first launch of a
                                         // kernel -- its code object is loaded then -- is a lone timeout and means nothing)
+    int xcc_rr = -1;                    // 1: the blocks of a grid run on XCD b % 8 (probed once); 0: not so; -1: not probed yet
     size_t cells_bound = 0;             // bytes the batch in progress may still allocate for its packed paths
     bool lds_attr_done[8] = {};         // k_search instantiations whose dynamic-LDS limit has been raised on this device
     bool lds_attr_coop[2] = {};         // ... and k_search_coop's
@@ -416,7 +413,6 @@ uint32_t ceil_log2(uint64_t v) {
 // Gives the memory of pool 0 back (a batch buffer did not fit beside it); the next batch sizes it again from what is free.
 void release_pool0(DevCtx& d) {
     if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
-        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);
     (void)hipStreamSynchronize(d.stream);
     d.tables[0].release();
     d.far[0].release();
@@ -639,8 +635,7 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
         nsolo = 0;
     nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
     if (nsolo != 0u) waves = std::min<uint32_t>(waves, (c.nwaves - nsolo) & ~((uint32_t)fx::WPB - 1u));
-    const bool masked = nsolo != 0u && d.stream_rest != nullptr;  // the head launch on XCDs of its own, the batch's on the others
-    if (masked) waves = std::min<uint32_t>(waves, ((uint32_t)d.n_cu_rest * 4u * (uint32_t)fx::OCC) & ~((uint32_t)fx::WPB - 1u));
+
     if (pool != 0 || nsolo != 0u || (uint64_t)nrun > (uint64_t)d.n_cu * live_main || d.share * h->mem_div > 1) live_main = 0u;
     // One query per BLOCK (k_search_coop: a searching wavefront and a stager that keeps the LDS tier of its open list in
     // shape, two SIMDs of a CU): for what a handful of long queries decide -- the head launch above, and batches small
@@ -656,8 +651,28 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
     const bool coop_ok = pool == 0 && !track && c.direct_ly > 0 && getenv("FXJPS_COOP") && atoi(getenv("FXJPS_COOP")) != 0;
     const bool coop_all = coop_ok && nsolo == 0u && live_main == 0u && nrun <= coop_max && nrun <= c.nwaves;
     if (coop_all) waves = std::min<uint32_t>(c.nwaves, nrun);  // blocks, one scratch slot each
+    // FXJPS_HEAD_XCC=1 (measurement: see DESIGN.md section 3.1c): the head launch on XCD 0 alone -- an L2 of its own --
+    // and the batch's launch on the other seven.  Needs the round-robin rule "block b runs on XCD b % 8" (probed once).
+    bool xcc_split = nsolo != 0u && live_solo == 1u && !coop_ok && d.n_cu == 256 && getenv("FXJPS_HEAD_XCC") && atoi(getenv("FXJPS_HEAD_XCC")) != 0;
+    if (xcc_split && d.xcc_rr < 0) {
+        d.xcc_rr = 0;
+        uint32_t* dp = nullptr;
+        uint32_t hp[64];
+        if (hipMalloc((void**)&dp, sizeof(hp)) == hipSuccess) {
+            hipLaunchKernelGGL(fx::k_xcc_probe, dim3(64), dim3(64), 0, d.stream, dp);
+            if (hipMemcpyAsync(hp, dp, sizeof(hp), hipMemcpyDeviceToHost, d.stream) == hipSuccess && hipStreamSynchronize(d.stream) == hipSuccess) {
+                d.xcc_rr = 1;
+                for (int b = 0; b < 64; b++)
+                    if (hp[b] != (uint32_t)(b % 8)) d.xcc_rr = 0;
+            }
+            (void)hipFree(dp);
+        }
+        (void)hipGetLastError();
+    }
+    if (xcc_split && (d.xcc_rr != 1 || nsolo > 32u)) xcc_split = false;
+    if (xcc_split) waves = std::min<uint32_t>(waves, (uint32_t)(d.n_cu / 8 * 7) * 4u * (uint32_t)fx::OCC);  // what seven XCDs hold at once
     if (pool == 0) d.waves_used = waves;
-    HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, 2 * sizeof(unsigned int), d.stream));
+    HIPCHK(h, hipMemsetAsync(d.d_next.p, 0, 4 * sizeof(unsigned int), d.stream));
     const dim3 block(fx::WAVE * fx::WPB);
     DBG("launch k_search pool=%d waves=%u nrun=%u buckets=%u far_cap=%u solo=%u x %u spread=%u coop=%d", pool, waves, nrun, c.nbuckets, c.far_cap, nsolo,
         live_solo, live_main, coop_all ? 2 : (coop_ok ? 1 : 0));
@@ -703,13 +718,21 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
             A.q0 = nsolo;
             A.nrun = nrun - nsolo;
             B.started = d.solo_started;
+            if (xcc_split) {  // eight times the blocks: every eighth one finds itself on XCD 0 and works
+                B.xcc_only = 1u;
+                B.slot_ctr = d.d_next.p + 3;
+                B.max_blocks = nsolo;
+                A.xcc_only = 0xFEu;
+                A.slot_ctr = d.d_next.p + 2;
+                A.max_blocks = waves / (uint32_t)fx::WPB;
+            }
             HIPCHK(h, hipEventRecord(d.ev_solo0, d.stream));
             HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_solo0, 0));
             HIPCHK(h, hipEventRecord(d.ev_hd0, d.stream_solo));
             if (coop_head)
                 hipLaunchKernelGGL(cfn, dim3(nsolo), dim3(fx::WAVE * 2), cpad, d.stream_solo, B);
             else
-            hipLaunchKernelGGL(fn, dim3(nsolo / live_solo), block, pad, d.stream_solo, B);
+            hipLaunchKernelGGL(fn, dim3((nsolo / live_solo) * (xcc_split ? 8u : 1u)), block, pad, d.stream_solo, B);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(d.ev_hd1, d.stream_solo));
             HIPCHK(h, hipEventRecord(d.ev_solo1, d.stream_solo));
@@ -720,8 +743,7 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
             d.solo_target += nsolo / live_solo;
             const auto t0 = std::chrono::steady_clock::now();
             bool late = false;
-            // (masked queues: the batch's launch cannot take the head launch's CUs -- nothing to wait for)
-            while (!masked && (int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
+            while ((int32_t)(__atomic_load_n(d.solo_started, __ATOMIC_ACQUIRE) - d.solo_target) < 0) {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
                     // (the counter did not arrive in time -- no PCIe atomics, a tool that serialises kernels: after three
                     // such waits in a row this device runs its batches as one launch; fxjps_timing_t::solo_timeouts counts them)
@@ -732,27 +754,19 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
             d.solo_timeouts += late ? 1 : 0;
             d.solo_timeouts_run = late ? d.solo_timeouts_run + 1 : 0;
         }
-        hipStream_t bst = d.stream;  // the stream of the batch's launch
-        if (masked) {
-            bst = d.stream_rest;
-            HIPCHK(h, hipStreamWaitEvent(bst, d.ev_solo0, 0));  // (the inputs, queued on d.stream, are in place)
-        }
-        if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, bst));
+        if (nsolo != 0u) HIPCHK(h, hipEventRecord(d.ev_bt0, d.stream));
         if (coop_all) {
             hipLaunchKernelGGL(cfn, dim3(waves), dim3(fx::WAVE * 2), 0, d.stream, A);
         } else if (live_main != 0u) {
             A.solo = live_main;
             hipLaunchKernelGGL(fn, dim3(waves / live_main), block, pad, d.stream, A);
         } else {
-            hipLaunchKernelGGL(fn, dim3(waves / fx::WPB), block, 0, bst, A);
+            // (split over the XCDs: as many blocks as the whole chip holds, an eighth of them leave at once)
+            hipLaunchKernelGGL(fn, dim3(xcc_split ? (unsigned)(d.n_cu * 2) : waves / fx::WPB), block, 0, d.stream, A);
         }
         HIPCHK(h, hipGetLastError());
         if (nsolo != 0u) {
-            HIPCHK(h, hipEventRecord(d.ev_bt1, bst));
-            if (masked) {
-                HIPCHK(h, hipEventRecord(d.ev_rest1, bst));
-                HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_rest1, 0));
-            }
+            HIPCHK(h, hipEventRecord(d.ev_bt1, d.stream));
             HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_solo1, 0));
         }
         if (pool == 0) d.had_solo = nsolo != 0u;
@@ -1217,8 +1231,7 @@ void drain_all(fxjps* h) {
     const std::string keep = h->err;
     for (auto& d : h->devs) {
         if (hipSetDevice(d.dev) == hipSuccess) {
-            if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
-        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);  // (a head launch may still be running)
+            if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);  // (a head launch may still be running)
             (void)hipStreamSynchronize(d.stream);
         }
         d.pool_clean[0] = d.pool_clean[1] = false;  // a search may have died half-way through a table
@@ -1271,30 +1284,7 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         // (FXJPS_ONE_STREAM=1: measurement aid -- no second stream, hence no head launches, on this handle: how the runtime
         // deals its hardware queues out over the streams of many handles)
         const bool one_stream = getenv("FXJPS_ONE_STREAM") && atoi(getenv("FXJPS_ONE_STREAM")) != 0;
-        // FXJPS_HEAD_XCDS=n (1 .. 4; 0 / unset: off): the head launch's stream is made with a CU mask of n XCDs and a third
-        // stream with the complement.  MI355X: 8 XCDs x 32 CUs, each XCD with its own L2; bit i of a queue's CU mask is CU
-        // i / 8 of XCD i % 8 (verified with tools/cumask_probe.hip: HW_REG_XCC_ID of the blocks of masked launches).
-        int head_xcds = 0;
-        if (const char* ev = getenv("FXJPS_HEAD_XCDS")) head_xcds = std::min(4, std::max(0, atoi(ev)));
-        const int ncu = prop.multiProcessorCount;
-        if (e == hipSuccess && !one_stream && head_xcds > 0 && ncu > 0 && ncu % 8 == 0 && ncu <= 1024) {
-            std::vector<uint32_t> mh((size_t)(ncu + 31) / 32, 0u), mr((size_t)(ncu + 31) / 32, 0u);
-            for (int i = 0; i < ncu; i++) ((i % 8) < head_xcds ? mh : mr)[(size_t)i >> 5] |= 1u << (i & 31);
-            if (hipExtStreamCreateWithCUMask(&d.stream_solo, (uint32_t)mh.size(), mh.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&d.stream_rest, (uint32_t)mr.size(), mr.data()) == hipSuccess &&
-                hipEventCreateWithFlags(&d.ev_rest1, hipEventDisableTiming) == hipSuccess) {
-                d.n_cu_rest = ncu / 8 * (8 - head_xcds);
-            } else {  // (no masked queues here: the plain second stream below)
-                (void)hipGetLastError();
-                if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
-        if (d.stream_rest) (void)hipStreamDestroy(d.stream_rest);
-        if (d.ev_rest1) (void)hipEventDestroy(d.ev_rest1);
-                if (d.stream_rest) (void)hipStreamDestroy(d.stream_rest);
-                d.stream_solo = d.stream_rest = nullptr;
-                d.n_cu_rest = 0;
-            }
-        }
-        if (e == hipSuccess && !one_stream && !d.stream_solo) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
+        if (e == hipSuccess && !one_stream) e = hipStreamCreateWithFlags(&d.stream_solo, hipStreamNonBlocking);
         if (e == hipSuccess && !one_stream) {
             // (fine-grained, mapped: the kernel counts with a system-scope atomic, the host polls)
             if (hipHostMalloc((void**)&d.solo_started, 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
@@ -1451,7 +1441,6 @@ void fxjps_destroy(fxjps_t* h) {
         if (d.dev < 0) continue;
         (void)hipSetDevice(d.dev);
         if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
-        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         d.occ.release();
         d.comp.release();
@@ -1507,8 +1496,7 @@ void fxjps_destroy(fxjps_t* h) {
         if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
         if (d.ev_solo1) (void)hipEventDestroy(d.ev_solo1);
         if (d.stream_solo) (void)hipStreamDestroy(d.stream_solo);
-        if (d.stream_rest) (void)hipStreamDestroy(d.stream_rest);
-        if (d.ev_rest1) (void)hipEventDestroy(d.ev_rest1);
+
         if (d.ev0) (void)hipEventDestroy(d.ev0);
         if (d.ev1) (void)hipEventDestroy(d.ev1);
         for (hipEvent_t ev : {d.ev_hd0, d.ev_hd1, d.ev_bt0, d.ev_bt1})
@@ -2081,7 +2069,6 @@ int fxjps_set_memory_share(fxjps_t* h, int32_t handles_per_device) {
                                    // a pool sized for the whole device would stay, and be credited to this handle's budget
             if (hipSetDevice(d.dev) == hipSuccess) {
                 if (d.stream_solo) (void)hipStreamSynchronize(d.stream_solo);
-        if (d.stream_rest) (void)hipStreamSynchronize(d.stream_rest);
                 (void)hipStreamSynchronize(d.stream);
             }
             for (int p = 0; p < 2; p++) {

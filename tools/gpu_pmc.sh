@@ -1,7 +1,8 @@
 #!/bin/bash
 # Instruction counters of one launch of the search kernel (run on the GPU box): VALU / SALU / LDS / VMEM instructions
 # per pop and per loop iteration.  Usage: [FX_QIDS=9206] tools/gpu_pmc.sh [tag] [nq]   (honours FXJPS_LIB)
-# The pops come from the run's own counters; iterations from a second run on the diagnostic build when it exists.
+# The pops come from the run's own counters; iterations from a second run on the diagnostic build when it exists
+# (FX_PROF_LIB: the diagnostic build that goes with FXJPS_LIB, e.g. a -DFXJPS_KN=8 pair).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-cur}
 NQ=${2:-10000}
@@ -9,7 +10,7 @@ OUT=gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p gpurun_out
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 tools/gpu_prof.py --noprof $NQ > $OUT.log 2>&1
 BATCHES=0
-if [ -f fuxi-planner_amd/libfxjps_prof.so ]; then BATCHES=$(timeout -k 10 200 python3 tools/gpu_prof.py $NQ 2>/dev/null | sed -n 's/.*batches \([0-9]*\):.*/\1/p' | head -1); fi
+if [ -f "${FX_PROF_LIB:-fuxi-planner_amd/libfxjps_prof.so}" ]; then BATCHES=$(timeout -k 10 200 python3 tools/gpu_prof.py $NQ 2>/dev/null | sed -n 's/.*batches \([0-9]*\):.*/\1/p' | head -1); fi
 f=$(find $OUT -name "*counter_collection.csv" | head -1)
 python3 - "$f" "$TAG" "$OUT.log" "${BATCHES:-0}" <<'PY'
 import csv,sys,re

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if "--noprof" not in sys.argv:
-    os.environ["FXJPS_LIB"] = os.path.join(ROOT, "fuxi-planner_amd", "libfxjps_prof.so")
+    os.environ["FXJPS_LIB"] = os.environ.get("FX_PROF_LIB") or os.path.join(ROOT, "fuxi-planner_amd", "libfxjps_prof.so")  # (FX_PROF_LIB: the diagnostic build of a variant)
 import fuxi_planner_amd as fx
 from fuxi_planner_amd import synth, _lib
 W = int(os.environ.get("FX_W", "1024"))

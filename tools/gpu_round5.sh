@@ -51,7 +51,18 @@ PY
 window)
   timeout -k 10 600 python -m pytest tests/test_map_updates_gpu.py -m gpu -q -s -x -k "window" > $OUT/window.log 2>&1; grep "window update\|passed\|failed" $OUT/window.log
   FXJPS_JD_WALK=0 timeout -k 10 600 python -m pytest tests/test_map_updates_gpu.py -m gpu -q -s -x -k "window" > $OUT/window_stream.log 2>&1; grep "window update\|passed\|failed" $OUT/window_stream.log
-  chk $OUT/window.log $OUT/window_stream.log;;
+  chk $OUT/window.log $OUT/window_stream.log
+  rm -rf $OUT/window_prof; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/window_prof -- python3 -m pytest tests/test_map_updates_gpu.py -m gpu -q -x -k "window" > $OUT/window_prof.log 2>&1
+  chk $OUT/window_prof.log
+  python3 - $OUT/window_prof <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    print("kernels of the window updates (rocprofv3 --stats): name, calls, average us")
+    for r in rows[:14]:
+        print("  %-60s %6s %9.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY
+  rm -rf $OUT/window_prof;;
 *)
   tools/gpu_round4.sh $TAG $s || exit $?;;
 esac
