@@ -151,7 +151,7 @@ struct DevCtx {
     DBuf<int32_t> d_wp_eo, d_wp_nkept, d_wp_kept, d_wp_cells, d_wp_len;
     DBuf<long long> d_wp_off;
     DBuf<int32_t> d_upd_xy;
-    DBuf<uint8_t> d_upd_val, d_upd_chg;
+    DBuf<uint8_t> d_upd_chg;
     DBuf<int> d_owner;        // [W][H], -1 at rest: which entry of an update list decides a cell it names several times
     bool owner_ready = false;
     // a partial rebuild's changed cells (k_derive_cellinfo -> k_jd_walk): marks [PW][NS], zero at rest; their list; counters
@@ -169,7 +169,6 @@ struct DevCtx {
     // pinned staging of a cell-update list: the caller's arrays are copied here before the asynchronous H2D copy, so
     // that they need not outlive the call (ev_upd: the last copy out of the staging buffers has completed)
     HBuf<int32_t> h_upd_xy;
-    HBuf<uint8_t> h_upd_val;
     hipEvent_t ev_upd = nullptr;
     bool upd_pending = false;
     HBuf<int32_t> h_len, h_cells;
@@ -334,20 +333,22 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
                 HIPCHK(h, d.d_chglist.ensure((size_t)(na + nb)));
                 chg = fx::ChangeOut{d.d_chgmap.p, d.d_chglist.p, d.d_chgcnt.p, (uint32_t)(na + nb), fx::MapRange{d.bx0, d.bx1, d.by0, d.by1}};
             }
-            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa, chg);
-            chg.B = fx::MapRange{1, 0, 1, 0};  // (the box lies in the rows just done)
-            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sb, chg);
+            hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa, sb, chg);
         } else {
             const long long ncell = (long long)d.PW * d.PH;
             hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p,
-                               fx::MapRange{0, d.PW - 1, 0, d.PH - 1}, chg);
+                               fx::MapRange{0, d.PW - 1, 0, d.PH - 1}, fx::MapRange{1, 0, 1, 0}, chg);
         }
         {  // the diagonal scan words: a function of the cell infos (and the occupancy) cell by cell -- of the cells above
             const fx::DiagRange dr{box ? 0 : 1, d.bx0, d.bx1, d.by0, d.by1};
             const long long per = box ? (long long)((d.bx1 >> 6) - (d.bx0 >> 6) + 1) + (((d.by1 - d.by0 + 63) >> 6) + 1) : (long long)d.WORDS;
             const long long nw = 4ll * G.DLINES * per;
-            hipLaunchKernelGGL(fx::k_derive_diag, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G,
-                               d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
+            if (box && chg.map != nullptr)  // (the changed cells alone, bit by bit)
+                hipLaunchKernelGGL(fx::k_diag_update, dim3((unsigned)std::min<long long>(((long long)chg.cap * 4 + 255) / 256, 256)), dim3(256), 0, d.stream,
+                                   d.occ.p, G, d.bm.p + (size_t)4 * d.LINES * d.WORDS, chg);
+            else
+                hipLaunchKernelGGL(fx::k_derive_diag, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G,
+                                   d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
             // ... and the jump distances: the goal-free jumps themselves, from every cell along every direction, read off
             // the scan words above (after an update: the entries whose old ray passes what the update can have changed)
             if (box && chg.map != nullptr) {
@@ -1477,7 +1478,6 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_wp_len.release();
         d.d_wp_off.release();
         d.d_upd_xy.release();
-        d.d_upd_val.release();
         d.d_upd_chg.release();
         d.d_owner.release();
         d.d_chgmap.release();
@@ -1489,7 +1489,6 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_offsets.release();
         d.h_counters.release();
         d.h_upd_xy.release();
-        d.h_upd_val.release();
         d.h_path1.release();
         if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
         if (d.solo_started) (void)hipHostFree(d.solo_started);
@@ -1778,15 +1777,15 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
             // update's copies and kernel must be through: ev_upd.
             if (d.upd_pending) HIPCHK(h, hipEventSynchronize(d.ev_upd));
             d.upd_pending = false;
-            HIPCHK(h, d.d_upd_xy.ensure((size_t)n * 2));
-            HIPCHK(h, d.d_upd_val.ensure((size_t)n));
-            HIPCHK(h, d.h_upd_xy.ensure((size_t)n * 2));
-            HIPCHK(h, d.h_upd_val.ensure((size_t)n));
+            // (coordinates and values travel as ONE copy: the values sit behind the coordinates in both buffers)
+            const size_t nwords = (size_t)n * 2 + ((size_t)n + 3) / 4;
+            HIPCHK(h, d.d_upd_xy.ensure(nwords));
+            HIPCHK(h, d.h_upd_xy.ensure(nwords));
             memcpy(d.h_upd_xy.p, xy, (size_t)n * 2 * sizeof(int32_t));
-            memcpy(d.h_upd_val.p, val, (size_t)n);
-            HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, d.h_upd_xy.p, (size_t)n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-            HIPCHK(h, hipMemcpyAsync(d.d_upd_val.p, d.h_upd_val.p, (size_t)n, hipMemcpyHostToDevice, d.stream));
+            memcpy(d.h_upd_xy.p + (size_t)n * 2, val, (size_t)n);
+            HIPCHK(h, hipMemcpyAsync(d.d_upd_xy.p, d.h_upd_xy.p, (size_t)n * 2 * sizeof(int32_t) + (size_t)n, hipMemcpyHostToDevice, d.stream));
         }
+        const uint8_t* d_val = reinterpret_cast<const uint8_t*>(d.d_upd_xy.p + (size_t)n * 2);
         if (n > 0) {
             HIPCHK(h, d.d_upd_chg.ensure((size_t)n));
             if (!d.owner_ready) {  // (streaming callers only: allocated with the first update of a grid)
@@ -1796,7 +1795,7 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
             }
             const unsigned nbk = (unsigned)((n + 255) / 256);
             hipLaunchKernelGGL(fx::k_update_claim, dim3(nbk), dim3(256), 0, d.stream, d.d_owner.p, d.W, d.H, d.d_upd_xy.p, (long long)n);
-            hipLaunchKernelGGL(fx::k_update_cells, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_val.p,
+            hipLaunchKernelGGL(fx::k_update_cells, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d_val,
                                (long long)n, d.d_upd_chg.p, d.d_owner.p);
             // the labels: a small update is united into them right away (the list is on the device now, not when the
             // maps are rebuilt); a large one, and every 64th small one, asks for the full relabelling

@@ -304,7 +304,8 @@ int fxjps_debug_read_maps(fxjps_t* h, int32_t which, void* buf, int64_t capacity
 /* Measurement aids of tools/ (not used by the planner's Python host code).  fxjps_debug_counters: the 64 raw device
  * counters of the last batch on the first context ([0] pops, [1] pushes, [2] far refills, [3] slow pops, [7] table wipes;
  * the rest is filled by the diagnostic build -DFXJPS_PROF only).  fxjps_debug_qstat: with FXJPS_QSTAT=1 in the
- * environment, 4 u64 per query of the last batch on the first context: start, end (100 MHz ticks), pops, wavefront. */
+ * environment, 4 u64 per query of the last batch on the first context: start, end (100 MHz ticks), pops, wavefront (low
+ * 24 bits) | shader-clock cycles of the search << 24. */
 int fxjps_debug_counters(fxjps_t* h, unsigned long long* out64);
 int fxjps_debug_qstat(fxjps_t* h, unsigned long long* out, int64_t nq);
 

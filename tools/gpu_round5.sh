@@ -2,9 +2,11 @@
 # One GPU-box session of round 5 (run through gpurun).  Usage: tools/gpu_round5.sh <tag> [steps...]
 #   every step of tools/gpu_round4.sh (tests quick bench lines one profiles busy multi stress), plus:
 #   cumask     tools/cumask_probe: where the blocks of CU-masked launches land (XCD / CU)
-#   headxcd    A/B of FXJPS_HEAD_XCDS x FXJPS_SOLO on config 2 (FX_HEAD="<xcds>:<solo> ...")
+#   headxcd    A/B of FXJPS_HEAD_XCC x FXJPS_SOLO on config 2 (FX_HEAD="<xcds>:<solo> ...")
 #   queues     c5pipe under rocprofv3 --kernel-trace for "<queues>:<K>[:one]" settings (FX_QK), tools/queue_map.py on each
-#   window     the 64 x 64 window update at 4096^2, walk / stream (tests/test_map_updates_gpu.py prints it)
+#   window     the 64 x 64 window update at 4096^2, walk / stream (tests/test_map_updates_gpu.py prints it), its kernels
+#   proxy2q    instruction counts and commits per iteration of batches of 16 and of 8 nodes (two queries per wavefront, by proxy)
+#   clock      tools/clock_probe.py: cycles and wall time of the longest queries, alone and inside their batch
 # Every step checks its logs for a GPU fault before the next program is started.
 : ${GRAFT_REPO_ROOT:?must run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}
 TAG=${1:-r5}; shift
@@ -18,9 +20,9 @@ case $s in
 cumask)
   timeout -k 10 120 tools/cumask_probe > $OUT/cumask.txt 2>&1; echo "cumask rc=$?"; cat $OUT/cumask.txt; chk $OUT/cumask.txt;;
 headxcd)
-  for hs in ${FX_HEAD:-0:16 1:16 1:32 2:32 2:48}; do
+  for hs in ${FX_HEAD:-0:16 1:16 1:24 1:32 0:32}; do
     x=${hs%%:*}; n=${hs##*:}
-    FXJPS_HEAD_XCDS=$x FXJPS_SOLO=$n timeout -k 10 300 python bench.py --workload ${FX_HEAD_WL:-c2} --steps ${FX_STEPS:-8} --warmup 3 --no-also --no-cpu-baseline > $OUT/head_${x}_$n.json 2> $OUT/head_${x}_$n.err; rc=$?
+    FXJPS_HEAD_XCC=$x FXJPS_SOLO=$n timeout -k 10 300 python bench.py --workload ${FX_HEAD_WL:-c2} --steps ${FX_STEPS:-8} --warmup 3 --no-also --no-cpu-baseline > $OUT/head_${x}_$n.json 2> $OUT/head_${x}_$n.err; rc=$?
     chk $OUT/head_${x}_$n.err
     python3 - $OUT/head_${x}_$n.json $x $n $rc <<'PY'
 import json, sys
@@ -63,6 +65,18 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
         print("  %-60s %6s %9.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
   rm -rf $OUT/window_prof;;
+proxy2q)
+  # Two queries per wavefront, by proxy: what a batch of 8 nodes commits and what its iteration costs,
+  # beside the batch of 16 -- on a full chip (40 000 queries of config 4's stream: no head launch).  The variant libraries
+  # are built with -DFXJPS_KN=8 (tools/README.md).
+  tools/gpu_pmc.sh kn16 ${FX_PROXY_NQ:-40000} > $OUT/pmc_kn16.txt 2>&1; cat $OUT/pmc_kn16.txt; chk $OUT/pmc_kn16.txt gpurun_out/pmc_kn16.log
+  FXJPS_LIB=$PWD/fuxi-planner_amd/libfxjps_kn8.so FX_PROF_LIB=$PWD/fuxi-planner_amd/libfxjps_kn8_prof.so tools/gpu_pmc.sh kn8 ${FX_PROXY_NQ:-40000} > $OUT/pmc_kn8.txt 2>&1; cat $OUT/pmc_kn8.txt; chk $OUT/pmc_kn8.txt gpurun_out/pmc_kn8.log
+  for l in "" kn8; do
+    FXJPS_LIB=${l:+$PWD/fuxi-planner_amd/libfxjps_$l.so} timeout -k 10 300 python bench.py --workload c4shard --steps 3 --warmup 1 --no-also --no-cpu-baseline 2> $OUT/c4shard_${l:-kn16}.err | cut -c1-200
+    chk $OUT/c4shard_${l:-kn16}.err
+  done;;
+clock)
+  timeout -k 10 300 python tools/clock_probe.py c2 6 > $OUT/clock.txt 2>&1; cat $OUT/clock.txt; chk $OUT/clock.txt;;
 *)
   tools/gpu_round4.sh $TAG $s || exit $?;;
 esac

@@ -48,7 +48,7 @@ rank[np.argsort(-d, kind="stable")] = np.arange(nq)
 for i in np.argsort(-te)[:24]:
     qi = ids[i]
     print("  ends last: q %5d  rank %5d  dx %4d dy %4d  pops %6d  start %.1f  end %.1f ms  us/pop %.3f  wave %d" % (
-        qi, rank[qi], abs(s[qi, 0] - g[qi, 0]), abs(s[qi, 1] - g[qi, 1]), pops[i], ts[i] / 1e3, te[i] / 1e3, rate[i], int(q[qi, 3])))
+        qi, rank[qi], abs(s[qi, 0] - g[qi, 0]), abs(s[qi, 1] - g[qi, 1]), pops[i], ts[i] / 1e3, te[i] / 1e3, rate[i], int(q[qi, 3]) & 0xFFFFFF))
 for t in (40, 50, 60, 70, 80, 90):
     print("  still running at %d ms: %d" % (t, (te > t * 1e3).sum()))
 np.save(os.path.join(ROOT, "gpurun_out", "qstat_%s_%s.npy" % (wname, os.environ.get("FXJPS_WAVES", "full"))), q)
