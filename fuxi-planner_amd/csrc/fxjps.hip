@@ -652,9 +652,10 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
     const bool coop_ok = pool == 0 && !track && c.direct_ly > 0 && getenv("FXJPS_COOP") && atoi(getenv("FXJPS_COOP")) != 0;
     const bool coop_all = coop_ok && nsolo == 0u && live_main == 0u && nrun <= coop_max && nrun <= c.nwaves;
     if (coop_all) waves = std::min<uint32_t>(c.nwaves, nrun);  // blocks, one scratch slot each
-    // FXJPS_HEAD_XCC=1 (measurement: see DESIGN.md section 3.1c): the head launch on XCD 0 alone -- an L2 of its own --
+    // A library built with -DFXJPS_XCC=1 and FXJPS_HEAD_XCC=1 in the environment (measurement: see DESIGN.md section 3.1c,
+    // `make libfxjps_xcc.so`): the head launch on XCD 0 alone -- an L2 of its own --
     // and the batch's launch on the other seven.  Needs the round-robin rule "block b runs on XCD b % 8" (probed once).
-    bool xcc_split = nsolo != 0u && live_solo == 1u && !coop_ok && d.n_cu == 256 && getenv("FXJPS_HEAD_XCC") && atoi(getenv("FXJPS_HEAD_XCC")) != 0;
+    bool xcc_split = FXJPS_XCC != 0 && nsolo != 0u && live_solo == 1u && !coop_ok && d.n_cu == 256 && getenv("FXJPS_HEAD_XCC") && atoi(getenv("FXJPS_HEAD_XCC")) != 0;
     if (xcc_split && d.xcc_rr < 0) {
         d.xcc_rr = 0;
         uint32_t* dp = nullptr;

@@ -4,6 +4,7 @@ labels instead of relabelling the map.  After every update the derived device ma
 of a fresh upload of the same grid on a second handle; the component forest must keep together whatever the fresh labels
 keep together (it may be coarser where an update split a component: those queries are searched, not answered at once);
 plans on the updated handle equal the oracle's."""
+import os
 import time
 
 import numpy as np
@@ -111,8 +112,9 @@ def test_partial_rebuild_equals_fresh_upload(oracle, jd_mode, monkeypatch):
 
 
 def test_window_update_on_a_large_map_is_cheap():
-    """A 64 x 64 window re-observed on 4096 x 4096: the rebuild touches 66 lines and the rows / columns through them,
-    not 16 M cells and their labels (before: about 2 ms)."""
+    """A 64 x 64 window re-observed on 4096 x 4096: the rebuild touches 66 lines, the rows / columns through them and the
+    jump distances whose rays reach a changed cell (found from the changed cells backwards), not 16 M cells, their labels
+    and their 268 MB of records (round 2: about 2 ms; round 4, every record read: 0.27 ms; round 5: 0.09 ms)."""
     import fuxi_planner_amd as fx
     from fuxi_planner_amd import synth
     occ = synth.synth_grid(4096, 4096, 2, 0.20)
@@ -130,7 +132,7 @@ def test_window_update_on_a_large_map_is_cheap():
             ts.append(time.perf_counter() - t)
         ts = np.array(ts[8:]) * 1e3
         print("64x64 window update at 4096^2: median %.3f ms, max %.3f ms (host call, blocking)" % (np.median(ts), ts.max()))
-        assert np.median(ts) < 0.6
+        assert np.median(ts) < (0.6 if os.environ.get("FXJPS_JD_WALK") == "0" else 0.16)
 
 
 def test_odd_update_lists_and_several_contexts(oracle):

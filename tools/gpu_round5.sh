@@ -2,7 +2,7 @@
 # One GPU-box session of round 5 (run through gpurun).  Usage: tools/gpu_round5.sh <tag> [steps...]
 #   every step of tools/gpu_round4.sh (tests quick bench lines one profiles busy multi stress), plus:
 #   cumask     tools/cumask_probe: where the blocks of CU-masked launches land (XCD / CU)
-#   headxcd    A/B of FXJPS_HEAD_XCC x FXJPS_SOLO on config 2 (FX_HEAD="<xcds>:<solo> ...")
+#   headxcd    A/B of FXJPS_HEAD_XCC x FXJPS_SOLO on config 2 (FX_HEAD="<0|1>:<solo> ..."; needs `make -C fuxi-planner_amd libfxjps_xcc.so`)
 #   queues     c5pipe under rocprofv3 --kernel-trace for "<queues>:<K>[:one]" settings (FX_QK), tools/queue_map.py on each
 #   window     the 64 x 64 window update at 4096^2, walk / stream (tests/test_map_updates_gpu.py prints it), its kernels
 #   proxy2q    instruction counts and commits per iteration of batches of 16 and of 8 nodes (two queries per wavefront, by proxy)
@@ -22,7 +22,7 @@ cumask)
 headxcd)
   for hs in ${FX_HEAD:-0:16 1:16 1:24 1:32 0:32}; do
     x=${hs%%:*}; n=${hs##*:}
-    FXJPS_HEAD_XCC=$x FXJPS_SOLO=$n timeout -k 10 300 python bench.py --workload ${FX_HEAD_WL:-c2} --steps ${FX_STEPS:-8} --warmup 3 --no-also --no-cpu-baseline > $OUT/head_${x}_$n.json 2> $OUT/head_${x}_$n.err; rc=$?
+    FXJPS_LIB=$PWD/fuxi-planner_amd/libfxjps_xcc.so FXJPS_HEAD_XCC=$x FXJPS_SOLO=$n timeout -k 10 300 python bench.py --workload ${FX_HEAD_WL:-c2} --steps ${FX_STEPS:-8} --warmup 3 --no-also --no-cpu-baseline > $OUT/head_${x}_$n.json 2> $OUT/head_${x}_$n.err; rc=$?
     chk $OUT/head_${x}_$n.err
     python3 - $OUT/head_${x}_$n.json $x $n $rc <<'PY'
 import json, sys
