@@ -131,6 +131,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     last = {}
 
     def step(i):
+        last.clear()  # (the previous step's arrays go back to the allocator first: a step that has to fault in 23 MB of fresh pages for its cells is 1 ms slower)
         if streaming:  # one call per frame: cell updates + map rebuild + search of the persistent queries
             off, cells, cost, status = planner.replan_frame(*frames[i])
         else:

@@ -7,7 +7,9 @@ roofline.achieved.  Deterministic: depends only on the seeds.
 
     python tools/algo_bytes.py [c2 c2h1 c4shard c3 c5 c5low]     # default: all; c4 is derived from c4shard
 
-c3 counts a 2 000-query literal sample and extrapolates (x 50) -- the oracle needs ~0.5 M pops per query there; c4 is
+c3 counts all 100 000 queries in chunks of 2 500 (round 5; until then a 2 000-query sample x 50; FX_C3_SAMPLE=n for a
+sample) -- the oracle needs ~0.5 M pops per query there, the whole count takes ~ 25 min of 64 host threads, finished
+chunks are kept under gpurun_out/algo_parts/ and a later run goes on behind them; c4 is
 8 x the literal count of its first 125 000 queries; c5 holds one literal count per frame for the first 616 frames of
 the toggle stream (16 warm-up frames + the 600 frames SURVEY 8d prescribes; c5pipe is the same stream), c5low / c5local
 for the first 40.  Meant for a many-core host (the GPU box: ~5 min on 256 threads, c5 alone ~10 min).
@@ -29,7 +31,7 @@ WORKLOADS = {
                                                              "(the first eighth of the 1M-query stream, qseed 1), hchoice=2"),
     "c4": dict(C2, nq=1000000, strong=True, cpu_sample=20000,
                describe="BASELINE config 4: 1024x1024 grid (seed 1), 1000000 queries (qseed 1) split over the GPUs in contiguous shards, hchoice=2"),
-    "c3": dict(W=4096, H=4096, grid_seed=2, p=0.20, qseed=2, hchoice=2, max_path_len=4096, nq=100000, sample=2000, cpu_sample=512, cpu_threads=64,
+    "c3": dict(W=4096, H=4096, grid_seed=2, p=0.20, qseed=2, hchoice=2, max_path_len=4096, nq=100000, sample=int(os.environ.get("FX_C3_SAMPLE", "100000")), chunk=2500, cpu_sample=512, cpu_threads=64,
                describe="BASELINE config 3: 4096x4096 grid, 20% obstacles (seed 2), 100000 queries (qseed 2), hchoice=2"),
     "c5": dict(C2, qseed=5, nq=1000, max_path_len=2048, toggle_frac=0.05, toggle_seed=5, frames=616,  # 16 warm-up + the 600 frames of SURVEY 8d
                describe="BASELINE config 5, streaming replan: 1024x1024 grid (seed 1), per frame floor(0.05*W*H) occupied cells freed and as many "
@@ -87,7 +89,31 @@ def main():
         else:
             n = w.get("sample", w["nq"])
             s, g = oracle.synth_queries(occ, w["qseed"], n)
-            c, ln = count(occ, s, g, w["hchoice"], w["max_path_len"], nthreads=min(NT, w.get("cpu_threads", NT)))
+            if w.get("chunk"):
+                # a count that takes longer than one session on the box: chunk by chunk, every finished chunk kept under
+                # gpurun_out/ (a later run picks up where this one was cut)
+                c, lns = dict(cells=0, pushes=0, pops=0, algorithmic_bytes=0), []
+                part_dir = os.path.join(ROOT, "gpurun_out", "algo_parts")
+                os.makedirs(part_dir, exist_ok=True)
+                for lo in range(0, n, w["chunk"]):
+                    hi = min(n, lo + w["chunk"])
+                    pf = os.path.join(part_dir, "%s_%d_%d.json" % (name, lo, hi))
+                    have = [q for q in (pf, os.path.join(ROOT, ".algo_parts", os.path.basename(pf))) if os.path.exists(q)]  # (.algo_parts/: parts of
+                    if have:                                                                                   # an earlier session, carried to the box)
+                        with open(have[0]) as f:
+                            pc = json.load(f)
+                    else:
+                        cc, ln = count(occ, s[lo:hi], g[lo:hi], w["hchoice"], w["max_path_len"], nthreads=min(NT, w.get("cpu_threads", NT)))
+                        pc = dict(cc, lens=[int(v) for v in ln])
+                        with open(pf, "w") as f:
+                            json.dump(pc, f)
+                        print("%s queries %d .. %d counted, %.0f s" % (name, lo, hi, time.time() - t), flush=True)
+                    for k in c:
+                        c[k] += pc[k]
+                    lns += pc["lens"]
+                ln = np.array(lns)
+            else:
+                c, ln = count(occ, s, g, w["hchoice"], w["max_path_len"], nthreads=min(NT, w.get("cpu_threads", NT)))
             scale = w["nq"] / n
             rec.update(cells=int(c["cells"] * scale), pushes=int(c["pushes"] * scale), pops=int(c["pops"] * scale),
                        algorithmic_bytes=int(c["algorithmic_bytes"] * scale), bytes_per_query=c["algorithmic_bytes"] / n,
