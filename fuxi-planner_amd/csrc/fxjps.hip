@@ -170,7 +170,6 @@ struct DevCtx {
     // that they need not outlive the call (ev_upd: the last copy out of the staging buffers has completed)
     HBuf<int32_t> h_upd_xy;
     hipEvent_t ev_upd = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // the label update of a small list beside the partial rebuild of the maps
     bool upd_pending = false;
     HBuf<int32_t> h_len, h_cells;
     HBuf<uint32_t> h_path1;       // single calls: the search kernel writes the packed path of its one query here
@@ -1306,8 +1305,6 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         if (e == hipSuccess) e = hipEventCreate(&d.ev_bt0);
         if (e == hipSuccess) e = hipEventCreate(&d.ev_bt1);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_upd, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming);
         if (e != hipSuccess) {
             int rc = fail(nullptr, FXJPS_E_HIP, "device %d: %s", d.dev, hipGetErrorString(e));
             fxjps_destroy(h);
@@ -1495,8 +1492,6 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_upd_xy.release();
         d.h_path1.release();
         if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
-        if (d.ev_fork) (void)hipEventDestroy(d.ev_fork);
-        if (d.ev_join) (void)hipEventDestroy(d.ev_join);
         if (d.solo_started) (void)hipHostFree(d.solo_started);
         if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
         if (d.ev_solo1) (void)hipEventDestroy(d.ev_solo1);
@@ -1777,7 +1772,6 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
     // every device applies the same (small) update list; cheaper than re-broadcasting the grid
     for (auto& d : h->devs) {
         HIPCHK(h, hipSetDevice(d.dev));
-        bool forked = false;  // the label update runs on the second stream
         if (n > 0) {
             // The caller's arrays go through pinned staging buffers of the context: the call may return while the H2D
             // copies are still queued (fxjps_update_cells_deferred), and the caller owns its buffers again at once.
@@ -1809,21 +1803,12 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
             // maps are rebuilt); a large one, and every 64th small one, asks for the full relabelling
             static const long long small_max = getenv("FXJPS_CCL_SMALL") ? atoll(getenv("FXJPS_CCL_SMALL")) : 8192;  // (0: always relabel)
             if (!d.ccl_full && n <= small_max && d.ccl_small < 64) {
-                // The labels have nothing to do with the derived maps: when a partial rebuild follows in this call, the two
-                // small kernels run beside it on the handle's second stream (a window update at 4096^2 is a dozen launches of
-                // 3 .. 15 us: their number is what it costs).  Not beside a relabelling -- that writes the labels itself.
-                hipStream_t cst = d.stream;
-                if (derive && partial && d.stream_solo != nullptr && d.ev_fork != nullptr) {
-                    HIPCHK(h, hipEventRecord(d.ev_fork, d.stream));
-                    HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_fork, 0));
-                    cst = d.stream_solo;
-                    forked = true;
-                }
-                hipLaunchKernelGGL(fx::k_ccl_update, dim3(nbk), dim3(256), 0, cst, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_chg.p, (long long)n,
+                // (measured and dropped in round 5: the two label kernels on the handle's second stream, beside the partial
+                // rebuild that follows -- the fork / join events cost what the overlap gains: 0.091 ms either way)
+                hipLaunchKernelGGL(fx::k_ccl_update, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_chg.p, (long long)n,
                                    d.comp.p, 0);
-                hipLaunchKernelGGL(fx::k_ccl_update, dim3(nbk), dim3(256), 0, cst, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_chg.p, (long long)n,
+                hipLaunchKernelGGL(fx::k_ccl_update, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d.d_upd_chg.p, (long long)n,
                                    d.comp.p, 1);
-                if (forked) HIPCHK(h, hipEventRecord(d.ev_join, cst));
                 d.ccl_small++;
             } else {
                 d.ccl_full = true;
@@ -1842,7 +1827,6 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
             int rc = derive_maps(h, d, !partial);
             if (rc) return rc;
         }
-        if (forked) HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_join, 0));  // (everything behind this call finds the labels in place)
         if (n > 0) {  // the list's last readers are queued: the staging buffers are free again once this event has passed
             HIPCHK(h, hipEventRecord(d.ev_upd, d.stream));
             d.upd_pending = true;
