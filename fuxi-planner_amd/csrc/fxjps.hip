@@ -152,7 +152,6 @@ struct DevCtx {
     DBuf<long long> d_wp_off;
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_chg;
-    DBuf<unsigned int> d_bar;  // k_update_fused's grid barrier: {arrivals, blocks through}, zero at rest
     DBuf<int> d_owner;        // [W][H], -1 at rest: which entry of an update list decides a cell it names several times
     bool owner_ready = false;
     // a partial rebuild's changed cells (k_derive_cellinfo -> k_jd_walk): marks [PW][NS], zero at rest; their list; counters
@@ -1482,7 +1481,6 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_upd_xy.release();
         d.d_upd_chg.release();
         d.d_owner.release();
-        d.d_bar.release();
         d.d_chgmap.release();
         d.d_chglist.release();
         d.d_chgcnt.release();
@@ -1802,24 +1800,8 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
             // maps are rebuilt); a large one, and every 64th small one, asks for the full relabelling
             static const long long small_max = getenv("FXJPS_CCL_SMALL") ? atoll(getenv("FXJPS_CCL_SMALL")) : 8192;  // (0: always relabel)
             const bool ccl_now = !d.ccl_full && n <= small_max && d.ccl_small < 64;
-            // Lists of up to 16 384 cells on a handle that has the device to itself: claim, apply and the label update in ONE
-            // launch, the phases behind barriers over its (at most 64) blocks -- k_update_fused.  (Handles that share a device
-            // keep the separate launches: blocks that wait at a barrier for blocks the other handles' searches leave no room
-            // for would hold CUs for nothing.)  FXJPS_UPDATE_FUSED=0 / 2: never / also on shared devices (test aids).
-            const int fmode = getenv("FXJPS_UPDATE_FUSED") ? atoi(getenv("FXJPS_UPDATE_FUSED")) : 1;
-            const bool fused = n <= 16384 && fmode != 0 && (d.share * h->mem_div == 1 || fmode == 2);
-            if (fused) {
-                if (!d.d_bar.p) {
-                    HIPCHK(h, d.d_bar.ensure(4));
-                    HIPCHK(h, hipMemsetAsync(d.d_bar.p, 0, 4 * sizeof(unsigned int), d.stream));
-                }
-                hipLaunchKernelGGL(fx::k_update_fused, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d_val, (long long)n,
-                                   d.d_upd_chg.p, d.d_owner.p, d.comp.p, ccl_now ? 1 : 0, d.d_bar.p);
-                if (ccl_now)
-                    d.ccl_small++;
-                else
-                    d.ccl_full = true;
-            } else {
+            // (measured and dropped in round 5: these four list kernels as ONE launch with barriers over its blocks -- 19 -> 15 us,
+            // a 64 x 64 window update 0.091 -> 0.089 ms: a barrier across CUs costs what a launch costs)
             hipLaunchKernelGGL(fx::k_update_claim, dim3(nbk), dim3(256), 0, d.stream, d.d_owner.p, d.W, d.H, d.d_upd_xy.p, (long long)n);
             hipLaunchKernelGGL(fx::k_update_cells, dim3(nbk), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.d_upd_xy.p, d_val,
                                (long long)n, d.d_upd_chg.p, d.d_owner.p);
@@ -1833,7 +1815,6 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
                 d.ccl_small++;
             } else {
                 d.ccl_full = true;
-            }
             }
             HIPCHK(h, hipGetLastError());
             if (have_box) {  // padded coordinates: cell x sits at x + 1, its neighbours at x .. x + 2

@@ -48,7 +48,6 @@ def test_partial_rebuild_equals_fresh_upload(oracle, jd_mode, monkeypatch):
         monkeypatch.setenv("FXJPS_JD_WALK_MAX", "3")
     elif jd_mode == "stream":
         monkeypatch.setenv("FXJPS_JD_WALK", "0")
-        monkeypatch.setenv("FXJPS_UPDATE_FUSED", "0")  # (... and the list kernels as four launches, as in round 4)
     rng = np.random.default_rng(77)
     shapes = ((1024, 1024, 0.20), (700, 333, 0.3), (130, 2100, 0.15), (65, 64, 0.4), (600, 500, 0.0), (333, 800, 0.01), (512, 512, 0.04))
     with fx.Planner([0]) as p, fx.Planner([0]) as q:
@@ -136,18 +135,14 @@ def test_window_update_on_a_large_map_is_cheap():
         assert np.median(ts) < (0.6 if os.environ.get("FXJPS_JD_WALK") == "0" else 0.16)
 
 
-@pytest.mark.parametrize("fused", [2, 0])
-def test_odd_update_lists_and_several_contexts(oracle, fused, monkeypatch):
-    """(fused: the list kernels of an update as one launch with barriers over its blocks -- lists of up to 16 384 cells;
-    2: on this handle of three contexts as well -- or as four launches.)
-    Cells outside the grid in the list (ignored), an empty list, a list that repeats the resident values, a deferred
+def test_odd_update_lists_and_several_contexts(oracle):
+    """Cells outside the grid in the list (ignored), an empty list, a list that repeats the resident values, a deferred
     update followed by a new grid of another size (the leftover box must not reach into the new maps) -- on a handle with
     three contexts on the device (each applies the list and rebuilds its own maps): plans equal the oracle's and those
     of a one-context handle, the maps of the first context equal a fresh upload."""
     import fuxi_planner_amd as fx
     from fuxi_planner_amd import synth
     from test_gpu_parity import gpu_vs_oracle
-    monkeypatch.setenv("FXJPS_UPDATE_FUSED", str(fused))
     rng = np.random.default_rng(9)
     with fx.Planner([0, 0, 0]) as p3, fx.Planner([0]) as q:
         cur = synth.synth_grid(300, 200, 8, 0.25)
