@@ -286,7 +286,18 @@ def measure_c1(cx, reps=20):
         us, path = timed(lambda: p.plan(s, g, 2), reps)
         assert path == want, "c1: the path differs from the one captured from jps1.py"
         with contextlib.redirect_stdout(io.StringIO()):
-            us_m, r = timed(lambda: fx.jps1.method(m64, s, g, 2), reps)
+            us_m, r = timed(lambda: fx.jps1.method(m64, s, g, 2), reps)  # the map of the last tick again: not uploaded
+            assert r[0] == want
+            # ... and a map that differs from the last tick's (one cell in a far corner of the canvas, toggled every call):
+            # conversion + upload + map build + search
+            m_alt = [m64, m64.copy()]
+            m_alt[1][255, 255] = 1.0
+            tick = [0]
+
+            def new_map():
+                tick[0] += 1
+                return fx.jps1.method(m_alt[tick[0] & 1], s, g, 2)
+            us_new, r = timed(new_map, reps)
         assert r[0] == want
         us_c, rc = timed(lambda: oracle.plan(occ, s, g, 2, literal=False), reps)
         assert rc[0] == want
@@ -295,7 +306,7 @@ def measure_c1(cx, reps=20):
         ms_py = (time.perf_counter() - t0) * 1e3
         assert rp[0] == want
         canvas.append({"start": list(s), "goal": list(g), "jump_points": len(want), "us_per_call_resident_grid": us,
-                       "us_per_call_jps1_method": us_m, "kernel_us": p.timing()["search_kernel_ms"] * 1e3,
+                       "us_per_call_jps1_method": us_m, "us_per_call_jps1_method_new_map": us_new, "kernel_us": p.timing()["search_kernel_ms"] * 1e3,
                        "c_port_us_one_core": us_c, "python_restatement_ms_one_core": ms_py})
     maps = []
     for nm in z.files:

@@ -1524,7 +1524,9 @@ int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
     DevCtx& d0 = h->devs[0];
     HIPCHK(h, hipSetDevice(d0.dev));
     HIPCHK(h, hipMemcpyAsync(d0.occ.p, occ, (size_t)W * H, hipMemcpyHostToDevice, d0.stream));
-    HIPCHK(h, hipStreamSynchronize(d0.stream));
+    // (several contexts: the others copy from the first one's buffer on streams of their own.  One context: the map build
+    // is queued behind the copy on the same stream, and finish_set_grid waits for both -- one host wait per call)
+    if (h->devs.size() > 1) HIPCHK(h, hipStreamSynchronize(d0.stream));
     return finish_set_grid(h, W, H);
 }
 

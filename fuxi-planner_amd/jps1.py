@@ -20,11 +20,10 @@ def method(matrix, start, goal, hchoice):
     (jps1.py:207; `0` for start == goal)."""
     t0 = time.time()
     p = _planner.default_planner()
-    p.set_grid(matrix)
+    p.set_grid(matrix)  # (not uploaded again when it equals the resident grid)
     start = (int(start[0]), int(start[1]))
     goal = (int(goal[0]), int(goal[1]))
-    offsets, cells, cost, status = p.plan_batch([start], [goal], hchoice)
-    st = int(status[0])
+    st, cost0, cells = p.plan_one(start, goal, hchoice)
     if st == _lib.Q_BAD_START:
         # jps1.py indexes matrix[start] unchecked: IndexError (or silent numpy wrap-around for
         # negative indices, which no caller relies on)
@@ -34,6 +33,6 @@ def method(matrix, start, goal, hchoice):
     elapsed = round(time.time() - t0, 6)
     if st == 0:
         return (0, elapsed)
-    path = [(int(x), int(y)) for x, y in cells[offsets[0]:offsets[1]]]
-    print(0 if start == goal else float(cost[0]))
+    path = [(int(x), int(y)) for x, y in cells]
+    print(0 if start == goal else cost0)
     return (path, elapsed)

@@ -83,6 +83,7 @@ class Planner(object):
     def reserve_grid(self, W, H):
         """Allocate the device buffers of a W x H grid (what the next set_grid* call would allocate), nothing else."""
         self._chk(self._L.fxjps_reserve_grid(self._h, int(W), int(H)))
+        self._resident = None
 
     def set_grid_rank(self, occ, W, H):
         """Collective over the ranks of `for_rank`: rank 0 passes the uint8 [W][H] occupancy, the others None; ONE
@@ -117,9 +118,28 @@ class Planner(object):
             raise FxjpsError(rc, (self._L.fxjps_last_error(self._h) or b"").decode())
 
     # -- grid
+    @property
+    def shape(self):
+        """(W, H) of the resident grid, None before the first one."""
+        return self._shape
+
+    @shape.setter
+    def shape(self, v):  # (every call that replaces the resident grid sets it: what set_grid remembers is void then)
+        self._shape = v
+        self._resident = None
+
     def set_grid(self, matrix):
-        """Upload `matrix` (any 2-D array, matrix[x][y], obstacle iff == 1)."""
-        self.set_grid_occ(as_occ(matrix))
+        """Upload `matrix` (any 2-D array, matrix[x][y], obstacle iff == 1).
+
+        The node hands jps1.method its map anew every tick (global_planner_st.py:246-262 builds `mapu` from scratch each
+        time) whether or not a map message arrived in between: a matrix equal to the grid that is resident is not uploaded
+        again -- the comparison costs microseconds, the upload and the map build ~ 120 us at the node's map size."""
+        occ = as_occ(matrix)
+        r = self._resident
+        if r is not None and r.shape == occ.shape and np.array_equal(r, occ):
+            return
+        self.set_grid_occ(occ)
+        self._resident = occ  # (as_occ made a new array: nobody else holds it)
 
     def set_grid_occ(self, occ):
         """Upload a uint8 [W][H] occupancy array (non-zero = obstacle)."""
@@ -218,6 +238,7 @@ class Planner(object):
         val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
         if len(val) != len(xy):
             raise ValueError("xy and val lengths differ")
+        self._resident = None
         fn = self._L.fxjps_update_cells if rebuild else self._L.fxjps_update_cells_deferred
         self._chk(fn(self._h, _lib.ptr(xy, C.c_int32), _lib.ptr(val, C.c_uint8), len(val)))
 
@@ -290,6 +311,7 @@ class Planner(object):
         if len(val) != len(xy):
             raise ValueError("xy and val lengths differ")
         n = self._nq
+        self._resident = None
         offsets = np.zeros(n + 1, dtype=np.int64)
         status = np.zeros(n, dtype=np.int32)
         cost = np.zeros(n, dtype=np.float64)
@@ -303,16 +325,43 @@ class Planner(object):
         self.last_seconds = secs.value
         return offsets, cells, cost, status
 
+    def plan_one(self, start, goal, hchoice=2):
+        """One query -- the node's call, once per tick -- without the per-call allocations of plan_batch: the arrays of a
+        one-query call are kept, the cells come back with the call itself (no sizing call).  -> (status, cost, cells
+        int32[n, 2] view valid until the next call)."""
+        if self.shape is None:
+            raise FxjpsError(_lib.E_NOGRID, "plan before set_grid")
+        if hchoice not in (1, 2):
+            raise TypeError("unsupported operand type(s) for +: 'float' and 'NoneType' (hchoice must be 1 or 2)")
+        mpl = self.default_max_path_len()
+        o = getattr(self, "_one", None)
+        if o is None or o["mpl"] != mpl:
+            o = {"mpl": mpl, "s": np.zeros((1, 2), np.int32), "g": np.zeros((1, 2), np.int32), "off": np.zeros(2, np.int64),
+                 "st": np.zeros(1, np.int32), "cost": np.zeros(1, np.float64), "cells": np.zeros((mpl, 2), np.int32), "secs": C.c_double(0.0)}
+            o["args"] = (_lib.ptr(o["s"], C.c_int32), _lib.ptr(o["g"], C.c_int32), _lib.ptr(o["off"], C.c_int64), _lib.ptr(o["cells"], C.c_int32),
+                         _lib.ptr(o["st"], C.c_int32), _lib.ptr(o["cost"], C.c_double), C.byref(o["secs"]))
+            self._one = o
+        o["s"][0, 0], o["s"][0, 1] = start[0], start[1]
+        o["g"][0, 0], o["g"][0, 1] = goal[0], goal[1]
+        a = o["args"]
+        self._chk(self._L.fxjps_plan_batch_csr(self._h, a[0], a[1], 1, int(hchoice), mpl, a[2], a[3], mpl, a[4], a[5], a[6]))
+        st = int(o["st"][0])
+        if st == _lib.Q_PATH_TOO_LONG and mpl < self.shape[0] * self.shape[1] + 1:  # (rare: the general path grows the slot)
+            offsets, cells, cost, status = self.plan_batch([start], [goal], hchoice)
+            return int(status[0]), float(cost[0]), cells[offsets[0]:offsets[1]]
+        self.last_seconds = o["secs"].value
+        return st, float(o["cost"][0]), o["cells"][:max(st, 0)]
+
     def plan(self, start, goal, hchoice=2):
         """plan(start, goal) -> waypoint list [(x, y), ...] (jump points, start and
         goal inclusive); [] when there is no path."""
-        offsets, cells, cost, status = self.plan_batch([start], [goal], hchoice)
-        self.last_cost = float(cost[0])
-        if status[0] == _lib.Q_BAD_START:
+        st, cost, cells = self.plan_one(start, goal, hchoice)
+        self.last_cost = cost
+        if st == _lib.Q_BAD_START:
             raise IndexError("start %r is outside the %dx%d grid" % (tuple(start), self.shape[0], self.shape[1]))
-        if status[0] < 0:
-            raise FxjpsError(int(status[0]), "query failed")
-        return [(int(x), int(y)) for x, y in cells[offsets[0]:offsets[1]]]
+        if st < 0:
+            raise FxjpsError(st, "query failed")
+        return [(int(x), int(y)) for x, y in cells]
 
     def timing(self):
         t = _lib.Timing()

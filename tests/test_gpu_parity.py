@@ -208,6 +208,32 @@ def test_shim_error_behaviour(planner):
     assert r[0] is 0  # noqa: F632
 
 
+def test_shim_on_a_map_that_changes_between_ticks(oracle):
+    """The node calls jps1.method with a freshly built matrix every tick (global_planner_st.py:246-285).  The shim uploads it
+    only when it differs from the resident grid: ticks with the same map, a changed cell, the map of another size, the
+    first map again, a grid that something else made resident in between -- every answer is the oracle's on THAT tick's map."""
+    from fuxi_planner_amd import jps1, default_planner
+    rng = np.random.default_rng(21)
+    a = (rng.random((147, 112)) < 0.25).astype(np.float64)
+    b = a.copy()
+    b[rng.integers(0, 147, 30), rng.integers(0, 112, 30)] = 1
+    c = (rng.random((60, 90)) < 0.2).astype(np.float64)
+    ticks = [a, a.copy(), np.where(a == 1, 1.0, 100.0), b, b, c, a, a]
+    for t, m in enumerate(ticks):
+        occ = (m == 1).astype(np.uint8)
+        free = np.argwhere(occ == 0)
+        k = rng.integers(0, len(free), 2)
+        s, g = tuple(int(v) for v in free[k[0]]), tuple(int(v) for v in free[k[1]])
+        if t == 7:  # (somebody else used the process-wide planner in between)
+            default_planner().set_grid_occ(np.zeros((9, 9), np.uint8))
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            r = jps1.method(m, s, g, 2)
+        want, cost, _ = oracle.plan(occ, s, g, 2, literal=False)
+        assert (r[0] if r[0] else 0) == want, (t, s, g)
+        if want:
+            assert float(buf.getvalue()) == cost or s == g
+
+
 def test_random_small_goldens(planner):
     for rec in load_golden("random_small.json"):
         planner.set_grid_occ(grid_from_bits(rec["grid_bits"], rec["shape"]))

@@ -353,3 +353,49 @@ def test_hw_queue_setting_is_made_before_the_runtime_starts(monkeypatch):
     assert replan.configure_hw_queues() is None and "GPU_MAX_HW_QUEUES" not in os.environ
     with pytest.warns(RuntimeWarning, match="hardware queues"):
         replan._want_queues(12, "FramePipeline")
+
+
+def test_set_grid_does_not_upload_an_unchanged_matrix():
+    """Planner.set_grid(matrix) -- what jps1.method does every tick -- uploads only when the matrix differs from the grid
+    that is resident; whatever else changes the resident grid voids what it remembers.  (A stand-in for the library
+    counts the uploads: no GPU.)"""
+    import fuxi_planner_amd as fx
+
+    class Lib(object):
+        def __init__(self):
+            self.uploads, self.updates = 0, 0
+
+        def fxjps_set_grid(self, h, occ, W, H):
+            self.uploads += 1
+            return 0
+
+        def fxjps_update_cells(self, h, xy, val, n):
+            self.updates += 1
+            return 0
+
+        def fxjps_destroy(self, h):
+            pass
+
+    p = fx.Planner.__new__(fx.Planner)
+    p._L, p._h = Lib(), None
+    p.shape = None
+    m = (np.random.default_rng(1).random((40, 30)) < 0.3).astype(np.float64)
+    p.set_grid(m)
+    assert p._L.uploads == 1 and p.shape == (40, 30)
+    p.set_grid(m.copy())                      # the same map, a new array (the node rebuilds mapu every tick)
+    p.set_grid(np.where(m == 1, 1, 100))      # ... and anything that is not 1 is free (jps1.py:20-29): still the same grid
+    assert p._L.uploads == 1
+    m2 = m.copy()
+    m2[3, 4] = 1 - m2[3, 4]
+    p.set_grid(m2)
+    assert p._L.uploads == 2
+    p.set_grid(m2[:, :20])                    # another shape
+    assert p._L.uploads == 3
+    p.set_grid(m2[:, :20])
+    assert p._L.uploads == 3
+    p.update_cells(np.array([[1, 1]], np.int32), np.array([1], np.uint8))   # the resident grid changed behind set_grid's back
+    p.set_grid(m2[:, :20])
+    assert p._L.uploads == 4 and p._L.updates == 1
+    p.set_grid_occ(fx.as_occ(m))              # an upload that does not go through set_grid
+    p.set_grid(m2[:, :20])
+    assert p._L.uploads == 6
