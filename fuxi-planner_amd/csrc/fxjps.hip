@@ -385,6 +385,22 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
 
 int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     HIPCHK(h, hipSetDevice(d.dev));
+    // The search scratch is sized by the grid's shape.  A new grid of the SAME shape keeps the pools as they are -- what
+    // earlier searches left in the visited tables carries their generation tags and reads as empty, exactly as between two
+    // batches on one grid -- so a caller that uploads a changed map every tick (jps1.method) does not pay for sizing and
+    // wiping them again (~ 100 us of such a call); another shape makes the next batch size them anew.
+    // (While one of the tests' sizing knobs is set every new grid makes the next batch size the pools anew, as before.)
+    bool knob = false;
+    for (const char* k : {"FXJPS_TABLE_LOG2", "FXJPS_TABLE_SHIFT", "FXJPS_FAR_CAP", "FXJPS_POOL_BUDGET_MB", "FXJPS_POOL_FRAC", "FXJPS_DIRECT",
+                          "FXJPS_TABLE_SHRINK"})
+        knob = knob || getenv(k) != nullptr;
+    if (W != d.W || H != d.H || knob) {
+        d.pool_clean[0] = d.pool_clean[1] = false;
+        d.cfg[0] = ScratchCfg();
+        d.cfg[1] = ScratchCfg();
+        d.owner_ready = false;  // (the update lists' owner cells follow the grid's shape -- and are all -1 between two updates,
+        d.chg_ready = false;    // as the marks of the changed cells are all zero: a grid of the same shape finds them in order)
+    }
     d.W = W;
     d.H = H;
     d.PW = W + 2;
@@ -392,8 +408,6 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     d.NS = (d.PH + 63) & ~63;
     d.LINES = std::max(d.PW, d.PH);
     d.WORDS = (std::max(d.PW, d.PH) + 63) / 64;
-    d.owner_ready = false;  // (the update lists' owner cells follow the grid's shape)
-    d.chg_ready = false;    // (and so do the marks of the changed cells)
     d.tsh = 0;  // read-set tiles (streaming replan): at most 64 x 64 of them cover the grid
     while (((std::max(W, H) - 1) >> d.tsh) > 63) d.tsh++;
     HIPCHK(h, d.occ.ensure((size_t)W * H));
@@ -1237,6 +1251,7 @@ void drain_all(fxjps* h) {
             (void)hipStreamSynchronize(d.stream);
         }
         d.pool_clean[0] = d.pool_clean[1] = false;  // a search may have died half-way through a table
+        d.owner_ready = d.chg_ready = false;        // ... or an update half-way through its marks
     }
     (void)hipGetLastError();
     h->err = keep;
@@ -1374,9 +1389,6 @@ int fxjps_reserve_grid(fxjps_t* h, int32_t W, int32_t H) {
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, W, H);
         if (rc) return rc;
-        d.pool_clean[0] = d.pool_clean[1] = false;
-        d.cfg[0] = ScratchCfg();
-        d.cfg[1] = ScratchCfg();
     }
     return FXJPS_OK;
 }
@@ -1422,9 +1434,6 @@ int fxjps_set_grid_rank(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
     DevCtx& d0 = h->devs[0];
     int rc = alloc_grid(h, d0, W, H);
     if (rc) return rc;
-    d0.pool_clean[0] = d0.pool_clean[1] = false;
-    d0.cfg[0] = ScratchCfg();
-    d0.cfg[1] = ScratchCfg();
     HIPCHK(h, hipSetDevice(d0.dev));
     if (h->rank == 0) HIPCHK(h, hipMemcpyAsync(d0.occ.p, occ, (size_t)W * H, hipMemcpyHostToDevice, d0.stream));
     HIPCHK(h, hipStreamSynchronize(d0.stream));
@@ -1517,9 +1526,6 @@ int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, W, H);
         if (rc) return rc;
-        d.pool_clean[0] = d.pool_clean[1] = false;
-        d.cfg[0] = ScratchCfg();
-        d.cfg[1] = ScratchCfg();
     }
     DevCtx& d0 = h->devs[0];
     HIPCHK(h, hipSetDevice(d0.dev));
@@ -1539,9 +1545,6 @@ int fxjps_set_grid_device(fxjps_t* h, const void* d_occ, int32_t W, int32_t H) {
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, W, H);
         if (rc) return rc;
-        d.pool_clean[0] = d.pool_clean[1] = false;
-        d.cfg[0] = ScratchCfg();
-        d.cfg[1] = ScratchCfg();
     }
     DevCtx& d0 = h->devs[0];
     HIPCHK(h, hipSetDevice(d0.dev));
@@ -1574,9 +1577,6 @@ static int prepare_grid_impl(fxjps_t* h, const uint8_t* raw, int32_t W0, int32_t
         HIPCHK(h, d.d_raw.ensure((size_t)W0 * H0));
         int rc = alloc_grid(h, d, (int)W1, (int)H1);
         if (rc) return rc;
-        d.pool_clean[0] = d.pool_clean[1] = false;
-        d.cfg[0] = ScratchCfg();
-        d.cfg[1] = ScratchCfg();
         // every device pads and dilates the raw grid itself: cheaper than broadcasting the larger result
         HIPCHK(h, hipMemcpyAsync(d.d_raw.p, raw, (size_t)W0 * H0, hipMemcpyHostToDevice, d.stream));
         const long long n = W1 * H1;
@@ -1717,9 +1717,6 @@ int fxjps_set_grid_image(fxjps_t* h, const uint8_t* gray, int32_t rows, int32_t 
     for (auto& d : h->devs) {
         int rc = alloc_grid(h, d, cols, rows);  // map_pre = img[::-1].T: W = image columns, H = image rows   :182
         if (rc) return rc;
-        d.pool_clean[0] = d.pool_clean[1] = false;
-        d.cfg[0] = ScratchCfg();
-        d.cfg[1] = ScratchCfg();
     }
     DevCtx& d0 = h->devs[0];
     HIPCHK(h, hipSetDevice(d0.dev));
