@@ -352,6 +352,37 @@ def test_edge_cases(planner, oracle):
         planner.plan_batch(s, g, 0)
 
 
+def test_a_path_longer_than_the_default_slot(planner, oracle):
+    """64 x 64 cells, a serpentine of corridors with a notch above every other cell: 671 jump points, where the default slot
+    of a path holds max(256, 4 x 64).  plan_batch with the default slot grows it and plans again; the one-query call
+    (Planner.plan / jps1.method: their own arrays, the cells back with the call) hands over to it; an explicit slot that is
+    too small is reported, never truncated."""
+    from fuxi_planner_amd import _lib, jps1
+    W = H = 64
+    occ = np.ones((W, H), np.uint8)
+    rows = list(range(1, H - 2, 3))
+    for i, y in enumerate(rows):
+        occ[1:W - 1, y] = 0
+        occ[2:W - 2:2, y + 1] = 0  # the notches: a forced neighbour at every other cell of the corridor
+        if i + 1 < len(rows):
+            occ[W - 2 if i % 2 == 0 else 1, y:rows[i + 1] + 1] = 0
+    s, g = (1, rows[0]), ((W - 2) if (len(rows) - 1) % 2 == 0 else 1, rows[-1])
+    want, cost, _ = oracle.plan(occ, s, g, 2, literal=False)
+    assert len(want) > max(256, 4 * W)
+    planner.set_grid_occ(occ)
+    assert planner.default_max_path_len() == 256
+    off, cells, c, st = planner.plan_batch([s], [g], 2)
+    assert st[0] == len(want) and [tuple(v) for v in cells.tolist()] == want and c[0] == cost
+    assert planner.plan(s, g, 2) == want and planner.last_cost == cost
+    st1, c1, cells1 = planner.plan_one(s, g, 2)
+    assert st1 == len(want) and c1 == cost and [tuple(v) for v in np.asarray(cells1).tolist()] == want
+    off, cells, c, st = planner.plan_batch([s], [g], 2, max_path_len=300)
+    assert st[0] == _lib.Q_PATH_TOO_LONG and off[1] == 0 and c[0] == cost
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        r = jps1.method(occ.astype(np.float64), s, g, 2)
+    assert r[0] == want and float(buf.getvalue()) == cost
+
+
 def test_dense_and_csr_entry_points_agree(planner):
     import ctypes as C
     from fuxi_planner_amd import _lib, synth
