@@ -116,7 +116,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
             if frames_in_flight > 0:
                 wl["frames_in_flight"] = frames_in_flight
             from fuxi_planner_amd.replan import FramePipeline
-            pipe = FramePipeline(cx.dev_index, int(wl["frames_in_flight"]), occ, starts, goals, hchoice, mpl)
+            pipe = FramePipeline(cx.dev_index, int(wl["frames_in_flight"]), occ, starts, goals, hchoice, mpl, schedule=os.environ.get("FXJPS_BENCH_SCHEDULE", "free"))
         else:
             planner.set_queries(starts, goals, hchoice, mpl)
 
@@ -126,7 +126,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         if frames_in_flight > 0:
             wl["batches_in_flight"] = frames_in_flight
         from fuxi_planner_amd.replan import BatchPipeline
-        pipe = BatchPipeline(cx.dev_index, int(wl["batches_in_flight"]), occ)
+        pipe = BatchPipeline(cx.dev_index, int(wl["batches_in_flight"]), occ, schedule=os.environ.get("FXJPS_BENCH_SCHEDULE", "free"))
 
     last = {}
 

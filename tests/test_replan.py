@@ -42,8 +42,9 @@ def test_mark_then_due():
 
 
 def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
-    """FramePipeline (host logic, no GPU): frame f goes to handle f % K, which first applies the updates of the frames
-    the other handles planned, oldest first -- so that the grid a frame is planned on is the grid after ITS update."""
+    """FramePipeline (host logic, no GPU): with schedule "turn" frame f goes to handle f % K, with "free" to an idle one;
+    either way the handle first applies the updates of the frames the other handles planned, oldest first -- so that the
+    grid a frame is planned on is the grid after ITS update."""
     import threading
     import fuxi_planner_amd.planner as planner_mod
     from fuxi_planner_amd.replan import FramePipeline
@@ -97,9 +98,19 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
         g[xy[:, 0], xy[:, 1]] = val
         frames.append((xy, val))
         want.append(g.copy())
-    for k in (1, 3, 5):
+    for k in (1, 3, 5):  # whichever handle is idle takes the frame: every frame still sees the grid after its own update
         FakePlanner.made = []
         with FramePipeline(0, k, occ, np.zeros((4, 2), np.int32), np.ones((4, 2), np.int32)) as pipe:
+            assert pipe.schedule == "free"
+            futs = [pipe.submit(xy, val) for xy, val in frames]
+            got = [f.result() for f in futs]
+        assert len(FakePlanner.made) == k and all(p.closed for p in FakePlanner.made)
+        for fr in range(len(frames)):
+            assert np.array_equal(got[fr], want[fr]), (k, fr)
+        assert sum(p.calls.count("r") for p in FakePlanner.made) == len(frames)
+    for k in (1, 3, 5):
+        FakePlanner.made = []
+        with FramePipeline(0, k, occ, np.zeros((4, 2), np.int32), np.ones((4, 2), np.int32), schedule="turn") as pipe:
             futs = [pipe.submit(xy, val) for xy, val in frames]
             got = [f.result() for f in futs]
         assert len(FakePlanner.made) == k and all(p.closed for p in FakePlanner.made)
@@ -117,7 +128,7 @@ def test_frame_pipeline_hands_every_handle_every_update_in_order(monkeypatch):
         pass
 
     FakePlanner.made = []
-    pipe = FramePipeline(0, 2, occ, np.zeros((4, 2), np.int32), np.ones((4, 2), np.int32))
+    pipe = FramePipeline(0, 2, occ, np.zeros((4, 2), np.int32), np.ones((4, 2), np.int32), schedule="turn")
     orig = FakePlanner.made[1].replan_frame
     FakePlanner.made[1].replan_frame = lambda xy, val: (_ for _ in ()).throw(Boom("device lost"))
     f0 = pipe.submit(*frames[0])
@@ -173,10 +184,17 @@ def test_batch_pipeline_hands_the_batches_out_in_turn(monkeypatch):
     occ = (np.random.default_rng(4).random((10, 7)) < 0.3).astype(np.uint8)
     for k in (1, 2, 4):
         FakePlanner.made = []
-        with BatchPipeline(0, k, occ) as pipe:
+        with BatchPipeline(0, k, occ, schedule="turn") as pipe:
             futs = [pipe.submit(np.full((3, 2), b, np.int32), np.zeros((3, 2), np.int32), 1 + b % 2, 64) for b in range(11)]
             got = [f.result() for f in futs]
         assert got == [(b, int(occ.sum()), 1 + b % 2, 64) for b in range(11)]
         assert len(FakePlanner.made) == k and all(p.closed and p.share == k for p in FakePlanner.made)
         for j, p in enumerate(FakePlanner.made):
             assert p.batches == list(range(j, 11, k))
+        FakePlanner.made = []
+        with BatchPipeline(0, k, occ) as pipe:  # (the default: whichever handle is idle)
+            assert pipe.schedule == "free"
+            futs = [pipe.submit(np.full((3, 2), b, np.int32), np.zeros((3, 2), np.int32), 1 + b % 2, 64) for b in range(11)]
+            got = [f.result() for f in futs]
+        assert got == [(b, int(occ.sum()), 1 + b % 2, 64) for b in range(11)]
+        assert sorted(b for p in FakePlanner.made for b in p.batches) == list(range(11))
