@@ -23,12 +23,18 @@ generator fuxi-planner_amd/synth.py):
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-N > 1, two ways (contiguous query shards, one broadcast of the grid over xGMI, no other collective):
-  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE set): one process per GPU,
-    rank r plans its own nq-query slice (weak scaling; c4: the r-th N-th of the 1 M queries), the grid is built on rank
-    0 and broadcast once with RCCL through torch.distributed;
+N > 1, two ways (contiguous query shards, one broadcast of the grid over xGMI, no other collective), neither of
+which imports torch:
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (any launcher that sets RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_ADDR / MASTER_PORT): one process per GPU, rank r plans its own nq-query slice (weak scaling; c4:
+    the r-th N-th of the 1 M queries); the ranks meet over a TCP socket (fuxi_planner_amd.ranks), rank 0 hands out the RCCL
+    id, the library broadcasts the grid (fxjps_create_rank / fxjps_set_grid_rank);
   * plain `python bench.py --gpus N` (no WORLD_SIZE): ONE process drives all N GPUs through the library's own
-    multi-device handle -- fxjps_create(n_dev = N): ncclCommInitAll + one ncclBroadcast, no torch anywhere.
+    multi-device handle -- fxjps_create(n_dev = N): ncclCommInitAll + one ncclBroadcast.
+An N > 1 line verifies itself outside the timed region (`config.verified`): the SHA-256 of the grid every device / rank
+holds equals rank 0's, a stratified sample of EVERY shard's results (>= 500 queries each) equals the C oracle's on rank 0 --
+lengths, float64 cost bytes, cells --, and the run FAILS (exit code 3) when the RCCL communicator does not span all N
+(unless FXJPS_BENCH_ONE_DEVICE marks the run as a one-device rehearsal).
 
 Prints ONE JSON line on rank 0 (the driver contract) with `roofline` (HBM bound, algorithmic bytes / HIP-event kernel
 time), at N = 1 `cpu_baseline` (the C oracle on the host cores, bounded sample), and -- default workload only --
@@ -109,9 +115,19 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     frames, g_last = [], occ
     pipe = None
     if streaming:
-        frames, g_last = make_frames(synth, occ, starts, goals, wl, warmup + steps)
-        if wl.get("frames_in_flight"):
-            if cx.world > 1 or cx.gpus > 1:
+        if cx.world > 1 and wl.get("frames_in_flight"):
+            raise SystemExit("c5pipe is a single-GPU workload")
+        ends_s, ends_g = starts, goals
+        if cx.world > 1:
+            # one grid on every rank: the toggle stream avoids the endpoints of ALL ranks' queries, every rank generates the
+            # same frames, and rank 0's list is the one that travels (RankPlanner.replan_frame: SURVEY 8e, "broadcast only
+            # the per-frame toggle list")
+            ends_s, ends_g = synth.synth_queries(occ, wl["qseed"], nq * cx.world)
+        frames, g_last = make_frames(synth, occ, ends_s, ends_g, wl, warmup + steps)
+        if cx.world > 1:
+            cx.sp.set_queries(ends_s, ends_g, hchoice, mpl)  # (this rank keeps [rank * nq, (rank + 1) * nq): the queries it drew above)
+        elif wl.get("frames_in_flight"):
+            if cx.gpus > 1:
                 raise SystemExit("c5pipe is a single-GPU workload")
             if frames_in_flight > 0:
                 wl["frames_in_flight"] = frames_in_flight
@@ -132,7 +148,9 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
 
     def step(i):
         last.clear()  # (the previous step's arrays go back to the allocator first: a step that has to fault in 23 MB of fresh pages for its cells is 1 ms slower)
-        if streaming:  # one call per frame: cell updates + map rebuild + search of the persistent queries
+        if streaming and cx.world > 1:  # rank 0's cell updates reach every rank over the rendezvous socket, then as below
+            off, cells, cost, status = cx.sp.replan_frame(*(frames[i] if cx.rank == 0 else (None, None)))[2:]
+        elif streaming:  # one call per frame: cell updates + map rebuild + search of the persistent queries
             off, cells, cost, status = planner.replan_frame(*frames[i])
         else:
             off, cells, cost, status = planner.plan_batch(starts, goals, hchoice, mpl)  # blocking: results are in host memory
@@ -195,20 +213,15 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
     if pipe is not None:
         k_ms = None
     k_all = [k_ms]
-    if cx.world > 1 and cx.rdv is not None:  # (no torch: maximum and per-rank kernel times over the rendezvous socket)
+    if cx.world > 1:  # (maximum and per-rank kernel times over the rendezvous socket)
         parts = cx.rdv.bcast(cx.rdv.gather([elapsed, k_ms]))
         elapsed = max(float(x[0]) for x in parts)
         k_all = [float(x[1]) for x in parts]
-    elif cx.world > 1:
-        t = cx.torch.tensor([elapsed, k_ms], dtype=cx.torch.float64, device=cx.tdev)
-        allk = [cx.torch.zeros_like(t) for _ in range(cx.world)]
-        cx.dist.all_gather(allk, t)
-        elapsed = max(float(x[0]) for x in allk)
-        k_all = [float(x[1]) for x in allk]
     elif per_ctx is not None and len(per_ctx) > 1:
         k_all = [c["kernel_ms"] for c in per_ctx]
     if (status < 0).any():
         raise SystemExit("bench: %d queries failed" % int((status < 0).sum()))
+    verified = verify_multi(cx, wl, occ, g_last if streaming else occ, starts, goals, last.get("res"), strong, nq) if (cx.world > 1 or cx.gpus > 1) and pipe is None else None
     if cx.rank != 0:
         return None
 
@@ -233,7 +246,7 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         "frac": achieved / HBM_PEAK_GBS if achieved else None, "retried": int(retried), "reused": reused, "direct": direct,
         "waves": waves, "waves_short": waves_short, "launches": launches, "wl": wl, "frames": frames,
         "launch_ms": ({"head": float(np.mean(head_ms)), "batch": float(np.mean(batch_ms))} if launches == 2 and head_ms else None),
-        "last": last.get("res"),
+        "last": last.get("res"), "verified": verified,
         "kernel": "fx::k_search<%d, %s, %s>" % (hchoice, "true" if (streaming and name not in ("c5", "c5pipe")) else "false", "true" if direct else "false"),
     }
     if streaming:
@@ -249,6 +262,60 @@ def measure(cx, name, steps, warmup, frames_in_flight=0):
         out["latency_ms"] = {"mean": float(lat.mean()), "p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                              "max": float(lat.max()), "frames": int(len(lat))}
     return out
+
+
+def _sample_ids(lo, hi, k):
+    """k query positions of the shard [lo, hi), evenly spread, its first and last among them"""
+    n = hi - lo
+    if n <= k:
+        return np.arange(lo, hi)
+    return np.unique(np.r_[lo + (np.arange(k, dtype=np.int64) * n) // k, hi - 1])
+
+
+def verify_multi(cx, wl, occ0, grid_now, starts, goals, res, strong, nq, per_shard=None):
+    """What makes an N > 1 line evidence (outside every timed region): (a) the SHA-256 of the grid each
+    context / rank holds resident equals the one rank 0 generated; (b) a stratified sample of EVERY shard's results of the
+    last step -- `per_shard` queries each, at least 500 -- equals the C oracle's on rank 0: lengths, float64 cost bytes,
+    cells.  Raises SystemExit(3) on any difference.  -> the `config.verified` record (rank 0; None elsewhere)."""
+    per_shard = per_shard or int(os.environ.get("FXJPS_BENCH_VERIFY_PER_SHARD", "500"))
+    want = hashlib.sha256(np.ascontiguousarray(grid_now).tobytes()).hexdigest()
+    off, cells, cost, status = res
+    hc, mpl = wl["hchoice"], wl["max_path_len"]
+    if cx.world > 1:
+        hashes = cx.sp.grid_hashes()
+        lo, hi = 0, len(starts)  # (this rank's own queries: it drew them itself)
+        ids = _sample_ids(lo, hi, per_shard)
+        picked = [np.concatenate([cells[off[q]:off[q + 1]] for q in ids] or [np.zeros((0, 2), np.int32)]),
+                  np.array([off[q + 1] - off[q] for q in ids], np.int64)]
+        parts = cx.rdv.gather((starts[ids], goals[ids], status[ids], cost[ids], picked[0], picked[1]))
+        shards = parts if cx.rank == 0 else None
+    else:
+        hashes = [hashlib.sha256(cx.planner.get_grid(c).tobytes()).hexdigest() for c in range(cx.gpus)]
+        shards = []
+        for r in range(cx.gpus):  # the library's contiguous shards of the batch (fxjps.hip plan_core: nq * r / nd)
+            lo, hi = len(starts) * r // cx.gpus, len(starts) * (r + 1) // cx.gpus
+            ids = _sample_ids(lo, hi, per_shard)
+            shards.append((starts[ids], goals[ids], status[ids], cost[ids],
+                           np.concatenate([cells[off[q]:off[q + 1]] for q in ids] or [np.zeros((0, 2), np.int32)]),
+                           np.array([off[q + 1] - off[q] for q in ids], np.int64)))
+    ok_hash = all(h == want for h in hashes)
+    if cx.rank != 0:
+        return None
+    if not ok_hash:
+        print("bench: the grid differs between devices / ranks: %s (rank 0 generated %s)" % (hashes, want), file=sys.stderr)
+        raise SystemExit(3)
+    from oracle import oracle  # the checker: never on the planner's path, never inside a timed region
+    checked = []
+    for r, (s_, g_, st_, co_, ce_, ln_) in enumerate(shards):
+        oc, ol, ocost, _ = oracle.plan_batch(grid_now, s_, g_, hc, literal=False, max_len=mpl, nthreads=min(os.cpu_count() or 1, 64))
+        keep = np.arange(oc.shape[1])[None, :] < np.maximum(ol, 0)[:, None]
+        if not (np.array_equal(ol, st_) and ocost.tobytes() == np.asarray(co_, np.float64).tobytes() and np.array_equal(oc[keep], ce_)
+                and np.array_equal(np.maximum(ol, 0), ln_)):
+            print("bench: shard %d of %d disagrees with the oracle (lengths / float64 cost bytes / cells)" % (r, len(shards)), file=sys.stderr)
+            raise SystemExit(3)
+        checked.append(int(len(s_)))
+    return {"grid_hash_equal": True, "grid_sha256_16": want[:16], "devices_or_ranks_hashed": len(hashes), "shards_checked": len(shards),
+            "queries_checked_per_shard": checked, "against": "oracle/jps_oracle.c on rank 0: lengths, float64 cost bytes, cells of the last step"}
 
 
 def measure_c1(cx, reps=20):
@@ -370,7 +437,6 @@ def main():
         raise SystemExit("--gpus %d under torch.distributed.run needs --nproc-per-node %d (WORLD_SIZE is %d)" % (a.gpus, a.gpus, cx.world))
 
     import fuxi_planner_amd as fx
-    from fuxi_planner_amd.distributed import ShardedPlanner
 
     with open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")) as f:
         cx.WL = json.load(f)
@@ -379,26 +445,18 @@ def main():
         "BASELINE config 2:", "BASELINE config 2, batches back to back with 2 in flight (2 planner handles on the GPU take them in turn; "
         "every batch is the same fxjps_plan_batch call):"))
 
-    cx.torch = cx.dist = cx.sp = cx.rdv = None
-    # One process per GPU (WORLD_SIZE > 1, e.g. under torch.distributed.run): by default NO torch in the process -- the
-    # ranks meet over a TCP socket at MASTER_ADDR : MASTER_PORT + 1 (fuxi_planner_amd.ranks), rank 0 hands out the RCCL
-    # id, the library broadcasts the grid (fxjps_create_rank / fxjps_set_grid_rank).  FXJPS_BENCH_BACKEND=nccl | gloo keeps
-    # the round-3 path through torch.distributed (nccl: RCCL through torch; gloo: every rank on device 0, host broadcast).
-    # Bring-up aids for 1-GPU boxes (never set by the driver): FXJPS_BENCH_ONE_DEVICE=1 puts every rank (or every context
+    cx.sp = cx.rdv = None
+    # One process per GPU (WORLD_SIZE > 1, e.g. under torch.distributed.run): NO torch in the process -- the ranks meet over a
+    # TCP socket at MASTER_ADDR : MASTER_PORT + 1 (fuxi_planner_amd.ranks), rank 0 hands out the RCCL id, the library
+    # broadcasts the grid (fxjps_create_rank / fxjps_set_grid_rank).
+    # Bring-up aid for 1-GPU boxes (never set by the driver): FXJPS_BENCH_ONE_DEVICE=1 puts every rank (or every context
     # of the in-library handle) on device 0 -- everything but the collective, which RCCL refuses between ranks that share
     # a device: the grid bytes then travel over the rendezvous socket.
-    backend = os.environ.get("FXJPS_BENCH_BACKEND", "ranks")
     one_dev = bool(os.environ.get("FXJPS_BENCH_ONE_DEVICE"))
-    cx.dev_index = 0 if (backend == "gloo" or one_dev) else local_rank
-    if cx.world > 1 and backend != "ranks":
-        import torch
-        import torch.distributed as dist
-        cx.torch, cx.dist = torch, dist
-        torch.cuda.set_device(cx.dev_index)
-        dist.init_process_group(backend, rank=cx.rank, world_size=cx.world)  # "nccl" is RCCL on ROCm
-        cx.tdev = "cpu" if backend == "gloo" else "cuda:%d" % cx.dev_index
+    cx.one_dev = one_dev
+    cx.dev_index = 0 if one_dev else local_rank
 
-    if cx.world > 1 and backend == "ranks":
+    if cx.world > 1:
         from fuxi_planner_amd.ranks import RankPlanner, Rendezvous
         cx.rdv = Rendezvous.from_env()
         # (FXJPS_BENCH_TRY_RCCL=1 with FXJPS_BENCH_ONE_DEVICE=1: the ranks ask RCCL all the same -- it refuses ranks that share a
@@ -413,20 +471,10 @@ def main():
         else:
             devs = [cx.dev_index]
         cx.planner = fx.Planner(devs)
-        if cx.world > 1 and backend == "gloo":
-            cx.planner.set_memory_share(cx.world)
-        if cx.world > 1:
-            cx.sp = ShardedPlanner(cx.planner, device=cx.tdev)
 
     def sync():
         if cx.rdv is not None:
             cx.rdv.barrier()  # (the planner's calls are blocking: results are in host memory when they return)
-        elif cx.world > 1:
-            cx.torch.cuda.synchronize()
-            if backend == "nccl":
-                cx.dist.barrier(device_ids=[cx.dev_index])
-            else:
-                cx.dist.barrier()
     cx.sync = sync
 
     if a.workload == "c1":  # single calls: a latency, reported on its own line
@@ -439,6 +487,7 @@ def main():
                           "config": {"workload": "c1: " + r["describe"], "detail": r}}), flush=True)
         cx.planner.close()
         return
+    rc_final = 0
     m = measure(cx, a.workload, a.steps, a.warmup, a.frames_in_flight)
 
     # ---- the other BASELINE workloads, behind the headline's timed region (default invocation only)
@@ -468,18 +517,15 @@ def main():
         else:
             r = measure(cx, "c4", 2, 1)  # the 1 M queries of BASELINE config 4 split N ways: the strong-scaling workload
             if r:
-                also["c4"] = brief(r, ("kernel_ms_per_device",))
+                also["c4"] = brief(r, ("kernel_ms_per_device", "verified"))
 
     if cx.rank == 0:
         ci = cx.planner.comm_info()
-        if cx.world > 1 and cx.rdv is not None:
+        if cx.world > 1:
             rccl_ranks = ci["rccl_ranks"]
             collective = ("ncclBroadcast of the grid inside the library (fxjps_set_grid_rank), ncclCommCount = %d; rendezvous over TCP, no torch in the process" % rccl_ranks) \
                 if rccl_ranks else ("none: RCCL did not come up (%s), the grid bytes travel over the rendezvous socket" % cx.sp.rccl_error if getattr(cx.sp, "rccl_error", None)
                                     else "none: the ranks share one device (rehearsal), the grid bytes travel over the rendezvous socket")
-        elif cx.world > 1:
-            rccl_ranks = cx.world if backend == "nccl" else 0
-            collective = "torch.distributed %s broadcast of the grid, %d ranks" % ("nccl (RCCL)" if backend == "nccl" else backend, cx.world)
         else:
             rccl_ranks = ci["rccl_ranks"]
             collective = ("ncclBroadcast of the grid inside the library, ncclCommCount = %d" % rccl_ranks) if rccl_ranks else \
@@ -512,6 +558,7 @@ def main():
                        "queries_per_step": m["total_q"], "queries_on_rank0": m["n_local"], "grid": [m["W"], m["H"]], "hchoice": m["hchoice"],
                        "reachable_rank0": int((m["status"] > 0).sum()), "retried_on_large_scratch": m["retried"],
                        "parallelism": ("one process, fxjps_create(n_dev=%d)" % a.gpus) if cx.inlib else "queries sharded x%d, one process per GPU%s" % (a.gpus, ", torch-free ranks" if cx.rdv is not None else ""),
+                       "verified": m["verified"],
                        "torch_imported": "torch" in sys.modules,
                        "rccl_ranks": rccl_ranks, "collective": collective, "contexts": ci["contexts"] if cx.world == 1 else cx.world,
                        "kernel_ms_per_device": m["kernel_ms_per_device"], "resident_wavefronts": m["waves"], "wavefronts_cut_by_memory": m["waves_short"]},
@@ -584,9 +631,15 @@ def main():
                     also["c2pipe"] = {"error": (r.stderr or r.stdout)[-300:]}
             except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
                 also["c2pipe"] = {"error": repr(e)[:300]}
+        if (cx.world > 1 or cx.gpus > 1) and rccl_ranks != a.gpus:
+            if cx.one_dev:
+                out["config"]["rehearsal"] = "FXJPS_BENCH_ONE_DEVICE: every rank / context on device 0, no RCCL communicator -- not a multi-GPU measurement"
+            else:  # the line is printed (it says what happened), the run fails
+                out["config"]["error"] = "the RCCL communicator spans %d of %d ranks" % (rccl_ranks, a.gpus)
+                rc_final = 3
         if also:
             out["config"]["also"] = also
-        if cx.world == 1 and not cx.inlib and not a.no_cpu_baseline:
+        if not a.no_cpu_baseline:  # (at N > 1 too: rank 0's shard, the same leg)
             from oracle import oracle  # checker used as the CPU baseline ("port"), never by the planner
             ns = min(a.cpu_sample or wl.get("cpu_sample", m["wl"]["nq"]), m["n_local"])
             cores = min(os.cpu_count() or 1, 256)
@@ -627,10 +680,10 @@ def main():
     if cx.rdv is not None:
         cx.rdv.barrier()
         cx.rdv.close()
-    elif cx.world > 1:
-        cx.dist.destroy_process_group()
     if cx.planner is not None:
         cx.planner.close()
+    if rc_final:
+        raise SystemExit(rc_final)
 
 
 if __name__ == "__main__":

@@ -13,10 +13,10 @@ Q_NOPATH, Q_PATH_TOO_LONG, Q_BAD_START, Q_CAPACITY = 0, -1, -2, -3
 BACKEND_HIP = 1
 
 # every symbol include/fxjps.h declares (tests check the .so exports all of them)
-VERSION = 500  # FXJPS_VERSION of include/fxjps.h
+VERSION = 600  # FXJPS_VERSION of include/fxjps.h
 SYMBOLS = ("fxjps_version", "fxjps_timing_size", "fxjps_last_timing_sized", "fxjps_rank_preflight", "fxjps_reserve_grid",
            "fxjps_device_count", "fxjps_create", "fxjps_rank_unique_id", "fxjps_create_rank", "fxjps_set_grid_rank", "fxjps_destroy", "fxjps_last_error",
-           "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
+           "fxjps_set_grid", "fxjps_set_grid_device", "fxjps_prepare_grid", "fxjps_prepare_occupancy_msg", "fxjps_get_grid", "fxjps_get_grid_context", "fxjps_publish_map", "fxjps_set_grid_image", "fxjps_snapshot_image", "fxjps_update_cells", "fxjps_update_cells_deferred", "fxjps_set_queries", "fxjps_replan_frame", "fxjps_plan_batch",
            "fxjps_plan_batch_csr", "fxjps_last_cells", "fxjps_last_timing", "fxjps_last_timing_device", "fxjps_comm_info", "fxjps_set_memory_share", "fxjps_selftest_sqrt", "fxjps_selftest_wavemin", "fxjps_selftest_openlist", "fxjps_debug_read_nbmask", "fxjps_debug_read_maps", "fxjps_debug_counters", "fxjps_debug_qstat",
            "fxjps_waypoint_st", "fxjps_waypoint_ccst", "fxjps_waypoint_ccst_batch", "fxjps_waypoint_st_batch")
 
@@ -103,6 +103,8 @@ def load():
     L.fxjps_snapshot_image.argtypes = [vp, p_u8, C.c_int32, p_i32, p_i32]
     L.fxjps_get_grid.restype = C.c_int
     L.fxjps_get_grid.argtypes = [vp, p_u8, p_i32, p_i32]
+    L.fxjps_get_grid_context.restype = C.c_int
+    L.fxjps_get_grid_context.argtypes = [vp, C.c_int32, p_u8, p_i32, p_i32]
     L.fxjps_update_cells.restype = C.c_int
     L.fxjps_update_cells.argtypes = [vp, p_i32, p_u8, C.c_int64]
     L.fxjps_update_cells_deferred.restype = C.c_int

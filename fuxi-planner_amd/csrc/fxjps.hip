@@ -29,7 +29,9 @@ using fx::GridDev;
 using fx::SearchArgs;
 using fx::TEnt;
 
-std::string g_create_error;
+// (handles are created from threads: the text of a failed fxjps_create* belongs to the calling thread, which is the one that
+// asks for it with fxjps_last_error(NULL))
+thread_local std::string g_create_error;
 
 // FXJPS_DEBUG=1 in the environment: progress lines on stderr (bring-up aid)
 bool dbg_on() {
@@ -46,6 +48,43 @@ bool dbg_on() {
             fflush(stderr);               \
         }                                 \
     } while (0)
+
+// Independent jobs side by side on host threads (one per context of a multi-device handle; slices of one large copy).
+// Nothing may leave the library as a C++ exception: a thread that cannot be created makes its job run on the calling
+// thread instead, and a job that throws (std::bad_alloc in a worker's vectors) is reported as FXJPS_E_NOMEM.  -> the first
+// non-zero result in job order.
+template <typename F>
+int run_side_by_side(size_t n, F&& job) {  // job(i) -> int
+    std::vector<int> rcs(n, FXJPS_OK);
+    const auto guarded = [&](size_t i) {
+        try {
+            rcs[i] = job(i);
+        } catch (const std::bad_alloc&) {
+            rcs[i] = FXJPS_E_NOMEM;
+        } catch (...) {
+            rcs[i] = FXJPS_E_HIP;
+        }
+    };
+    std::vector<std::thread> th;
+    try {
+        th.reserve(n);
+    } catch (...) {
+    }
+    for (size_t i = 1; i < n; i++) {
+        bool started = false;
+        try {
+            th.emplace_back(guarded, i);
+            started = true;
+        } catch (...) {  // std::system_error: no more threads
+        }
+        if (!started) guarded(i);
+    }
+    if (n > 0) guarded(0);
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < n; i++)
+        if (rcs[i]) return rcs[i];
+    return FXJPS_OK;
+}
 
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1076,17 +1115,11 @@ int plan_core(fxjps* h, const int32_t* starts, const int32_t* goals, int64_t nq,
         // launch's start counter, then the kernel), packs its paths and brings them back.  The devices never wait for each
         // other's host-side tail -- run one after the other, eight tails of ~ 23 ms each behind ~ 570 ms of parallel search
         // capped config 4 at 75 % strong-scaling efficiency by construction.  (The shards share nothing, jps1.py:183-192.)
-        std::vector<int> rcs((size_t)nd, FXJPS_OK);
-        std::vector<std::thread> th;
-        th.reserve((size_t)nd);
-        for (int r = 0; r < nd; r++)
-            th.emplace_back([&, r] {
-                int e = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
-                if (!e) e = finish_shard(h, h->devs[r], hchoice, max_len);
-                rcs[(size_t)r] = e;
-            });
-        for (auto& t : th) t.join();
-        for (int r = 0; r < nd && !rc; r++) rc = rcs[(size_t)r];
+        rc = run_side_by_side((size_t)nd, [&](size_t r) {
+            int e = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
+            if (!e) e = finish_shard(h, h->devs[r], hchoice, max_len);
+            return e;
+        });
         done = true;
     }
     for (int r = 0; r < nd && !rc && !done; r++) rc = run_shard(h, h->devs[r], starts, goals, hchoice, max_len);
@@ -1663,10 +1696,13 @@ int fxjps_prepare_occupancy_msg(fxjps_t* h, const int8_t* data, int32_t width, i
                              out_W, out_H, out_map_d, out_end_occu);
 }
 
-int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {
+int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) { return fxjps_get_grid_context(h, 0, out, out_W, out_H); }
+
+int fxjps_get_grid_context(fxjps_t* h, int32_t ctx, uint8_t* out, int32_t* out_W, int32_t* out_H) {
     if (!h) return FXJPS_E_ARG;
     if (!h->have_grid) return fail(h, FXJPS_E_NOGRID, "no grid");
-    DevCtx& d = h->devs[0];
+    if (ctx < 0 || ctx >= (int32_t)h->devs.size()) return fail(h, FXJPS_E_ARG, "context %d of %d", (int)ctx, (int)h->devs.size());
+    DevCtx& d = h->devs[(size_t)ctx];
     if (out_W) *out_W = d.W;
     if (out_H) *out_H = d.H;
     if (out) {
@@ -1682,7 +1718,7 @@ int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H) {
 // ------------------------------------------------------------------ wire / on-disk adapters
 namespace {
 // dst[(fb ? B-1-b : b)][(fa ? A-1-a : a)][0..ch) = map(src[a][b]) for src [A][B], dst [B][A][ch]
-int transpose_map(fxjps_t* h, DevCtx& d, const uint8_t* d_src, int A, int B, int fa, int fb, int mode, int ch, uint8_t* d_dst) {
+static int transpose_map(fxjps_t* h, DevCtx& d, const uint8_t* d_src, int A, int B, int fa, int fb, int mode, int ch, uint8_t* d_dst) {
     const dim3 grid((unsigned)((B + 31) / 32), (unsigned)((A + 31) / 32)), block(32, 8);
     hipLaunchKernelGGL(fx::k_transpose_map, grid, block, 0, d.stream, d_src, A, B, fa, fb, mode, ch, d_dst);
     HIPCHK(h, hipGetLastError());
@@ -1848,44 +1884,43 @@ static void host_copy(void* dst, const void* src, size_t bytes) {
         return;
     }
     const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    for (size_t i = 1; i < nt; i++) {
+    (void)run_side_by_side(nt, [=](size_t i) {
         const size_t o = i * per;
-        if (o >= bytes) break;
-        th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, std::min(per, bytes - o)); });
-    }
-    memcpy(dst, src, std::min(per, bytes));
-    for (auto& t : th) t.join();
+        if (o < bytes) memcpy((char*)dst + o, (const char*)src + o, std::min(per, bytes - o));
+        return 0;
+    });
 }
 
 // plan_core's results -> the caller's CSR arrays
-int emit_csr(fxjps_t* h, int64_t nq, int64_t* out_offsets, int32_t* out_cells_xy, int64_t cells_capacity, int32_t* out_len,
+static int emit_csr(fxjps_t* h, int64_t nq, int64_t* out_offsets, int32_t* out_cells_xy, int64_t cells_capacity, int32_t* out_len,
              double* out_cost) {
     int64_t base = 0;
     bool fits = true;
     // every context's slice of the caller's arrays: where it starts is a prefix sum over the shards' totals, the copies
     // themselves are independent -- one host thread per context when there are several
-    std::vector<std::thread> th;
-    const bool par = h->devs.size() > 1;
+    struct Put {
+        DevCtx* d;
+        int64_t base, total;
+        bool cells;
+    };
+    std::vector<Put> puts;
     for (auto& d : h->devs) {
         if (d.nq == 0) continue;
         const int64_t total = d.h_offsets.p[d.nq];
         const bool cells = out_cells_xy && base + total <= cells_capacity && total > 0;
         if (out_cells_xy && base + total > cells_capacity) fits = false;  // (out_cells_xy == NULL: sizing call, the cells stay in the handle for fxjps_last_cells())
-        DevCtx* dp = &d;
-        const auto put = [=] {
-            memcpy(out_len + dp->q0, dp->h_len.p, (size_t)dp->nq * sizeof(int32_t));
-            memcpy(out_cost + dp->q0, dp->h_cost.p, (size_t)dp->nq * sizeof(double));
-            for (int64_t i = 0; i < dp->nq; i++) out_offsets[dp->q0 + i] = base + dp->h_offsets.p[i];
-            if (cells) host_copy(out_cells_xy + 2 * base, dp->h_cells.p, (size_t)total * 2 * sizeof(int32_t));
-        };
-        if (par)
-            th.emplace_back(put);
-        else
-            put();
+        puts.push_back(Put{&d, base, total, cells});
         base += total;
     }
-    for (auto& t : th) t.join();
+    (void)run_side_by_side(puts.size(), [&](size_t i) {
+        const Put& u = puts[i];
+        const DevCtx* dp = u.d;
+        memcpy(out_len + dp->q0, dp->h_len.p, (size_t)dp->nq * sizeof(int32_t));
+        memcpy(out_cost + dp->q0, dp->h_cost.p, (size_t)dp->nq * sizeof(double));
+        for (int64_t k = 0; k < dp->nq; k++) out_offsets[dp->q0 + k] = u.base + dp->h_offsets.p[k];
+        if (u.cells) host_copy(out_cells_xy + 2 * u.base, dp->h_cells.p, (size_t)u.total * 2 * sizeof(int32_t));
+        return 0;
+    });
     if (out_offsets) out_offsets[nq] = base;
     h->last_nq = nq;
     if (!fits) return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, batch needs %lld", (long long)cells_capacity, (long long)base);
@@ -2022,22 +2057,22 @@ int fxjps_last_cells(fxjps_t* h, int32_t* out_cells_xy, int64_t cells_capacity) 
     if (base > cells_capacity)
         return fail(h, FXJPS_E_ARG, "out_cells_xy holds %lld pairs, the last batch has more", (long long)cells_capacity);
     base = 0;
-    std::vector<std::thread> th;  // (several contexts: their slices are copied side by side, as in emit_csr)
-    const bool par = h->devs.size() > 1;
+    struct Put {
+        int32_t* dst;
+        const int32_t* src;
+        int64_t total;
+    };
+    std::vector<Put> puts;  // (several contexts: their slices are copied side by side, as in emit_csr)
     for (auto& d : h->devs) {
         if (d.nq == 0 || !d.h_offsets.p) continue;
         const int64_t total = d.h_offsets.p[d.nq];
-        if (total > 0) {
-            int32_t* dst = out_cells_xy + 2 * base;
-            const int32_t* src = d.h_cells.p;
-            if (par)
-                th.emplace_back([=] { host_copy(dst, src, (size_t)total * 2 * sizeof(int32_t)); });
-            else
-                host_copy(dst, src, (size_t)total * 2 * sizeof(int32_t));
-        }
+        if (total > 0) puts.push_back(Put{out_cells_xy + 2 * base, d.h_cells.p, total});
         base += total;
     }
-    for (auto& t : th) t.join();
+    (void)run_side_by_side(puts.size(), [&](size_t i) {
+        host_copy(puts[i].dst, puts[i].src, (size_t)puts[i].total * 2 * sizeof(int32_t));
+        return 0;
+    });
     return FXJPS_OK;
 }
 
@@ -2284,13 +2319,10 @@ int fxjps_waypoint_st_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, cons
                 bad[(size_t)t] = 1;
         }
     };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; t++) th.emplace_back(work, t);
-        for (auto& x : th) x.join();
-    }
+    (void)run_side_by_side((size_t)nt, [&](size_t t) {
+        work((int)t);
+        return 0;
+    });
     for (int b : bad)
         if (b) return fail(h, FXJPS_E_ARG, "fxjps_waypoint_st failed on a path");
     return FXJPS_OK;

@@ -64,7 +64,7 @@ int fxjps_waypoint_st(const int32_t* cells, int32_t n, const int32_t* map_start,
 
 namespace {
 // global_planner_ccst.py:258-283 on the sub-map [x0, x1) x [y0, y1) of occ; a is the end point named p1 there, b p2.
-bool line_is_free(const uint8_t* occ, int32_t W, int32_t H, const int32_t* a, const int32_t* b) {
+static bool line_is_free(const uint8_t* occ, int32_t W, int32_t H, const int32_t* a, const int32_t* b) {
     const int x0 = std::min(a[0], b[0]), x1 = std::max(a[0], b[0]), y0 = std::min(a[1], b[1]), y1 = std::max(a[1], b[1]);
     const int cx1 = std::min(x1, (int)W), cy1 = std::min(y1, (int)H);  // slices clip at the array bounds
     bool any = false;

@@ -147,6 +147,7 @@ class Planner(object):
         if occ.ndim != 2:
             raise ValueError("grid must be 2-D")
         W, H = occ.shape
+        self._resident = None  # (a failing upload leaves the handle without a grid, or with half of this one: nothing is resident)
         self._chk(self._L.fxjps_set_grid(self._h, _lib.ptr(occ, C.c_uint8), W, H))
         self.shape = (W, H)
 
@@ -196,12 +197,13 @@ class Planner(object):
         self.shape = (W.value, H.value)
         return (s[0], s[1]), (g[0], g[1]), (md[0], md[1]), self.shape, eo.value
 
-    def get_grid(self):
-        """The resident uint8 [W][H] occupancy grid (e.g. the prepared map the node publishes)."""
+    def get_grid(self, context=0):
+        """The resident uint8 [W][H] occupancy grid (e.g. the prepared map the node publishes); of a multi-device handle:
+        the bytes context `context` holds (equal on every device after the broadcast)."""
         W, H = C.c_int32(), C.c_int32()
-        self._chk(self._L.fxjps_get_grid(self._h, None, C.byref(W), C.byref(H)))
+        self._chk(self._L.fxjps_get_grid_context(self._h, int(context), None, C.byref(W), C.byref(H)))
         out = np.empty((W.value, H.value), dtype=np.uint8)
-        self._chk(self._L.fxjps_get_grid(self._h, _lib.ptr(out, C.c_uint8), None, None))
+        self._chk(self._L.fxjps_get_grid_context(self._h, int(context), _lib.ptr(out, C.c_uint8), None, None))
         return out
 
     # -- wire / on-disk adapters (SURVEY.md 8f, N3)

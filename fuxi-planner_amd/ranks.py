@@ -13,8 +13,15 @@ library's `ncclBroadcast` over xGMI (`fxjps_set_grid_rank`); results stay on the
     lo, hi, off, cells, cost, status = rp.plan_local(starts, goals)   # this rank's contiguous shard
     merged = rp.gather(off, cells, cost, status)      # rank 0: the batch in query order, byte-identical to one GPU
 
-No torch import anywhere on this path.  `fuxi_planner_amd.distributed.ShardedPlanner` is the same thing inside an
-existing `torch.distributed` process group, for callers that have one.
+Streaming replans (BASELINE config 5 on more than one GPU, SURVEY 8e: "broadcast only the per-frame toggle list"):
+
+    rp.set_queries(starts, goals)                     # every rank keeps its contiguous shard of the persistent queries
+    lo, hi, off, cells, cost, status = rp.replan_frame(xy, val)   # rank 0 passes the frame's cell updates (~ 420 KB at
+                                                      # config 5); they travel over the socket, never the grid
+    rp.grid_hashes()                                  # SHA-256 of every rank's resident grid, on every rank
+
+No torch import anywhere on this path.  (tools/torch_group.py -- not part of the package -- wraps the planner the same way
+inside an existing `torch.distributed` process group, for hosts that have one.)
 """
 import hashlib
 import hmac
@@ -181,6 +188,17 @@ class Rendezvous(object):
         self.sock = None  # other ranks: the socket to rank 0
         self.port = None  # the port the star was built on
         self.key = run_key(addr, port, world, token)
+        # Every connection gets a key of its own once both sides have shown that they hold the run's key: HMAC(run key,
+        # the two nonces of the greeting) -- frames of one connection, or of an earlier run on the same port, authenticate
+        # nowhere else.  A DATA frame is at most max_frame bytes (FXJPS_RDV_MAX_FRAME, default 1 GiB: the largest thing
+        # that travels is a grid or a shard's result arrays): a length beyond it is refused before a byte of payload is read.
+        self._keys = {}
+        self.max_frame = int(os.environ.get("FXJPS_RDV_MAX_FRAME", str(1 << 30)))
+        if (token is None and not os.environ.get("FXJPS_RDV_TOKEN") and not os.environ.get("TORCHELASTIC_RUN_ID")
+                and addr not in ("127.0.0.1", "localhost", "::1") and int(world) > 1):
+            import warnings
+            warnings.warn("fuxi_planner_amd.ranks: rendezvous on %s without FXJPS_RDV_TOKEN -- the frames are authenticated with a key "
+                          "anybody who can reach the port can compute; hand every rank a secret token" % addr, RuntimeWarning, stacklevel=2)
         if io_timeout is None:
             io_timeout = float(os.environ.get("FXJPS_RDV_IO_TIMEOUT", "900"))
         self.io_timeout = io_timeout
@@ -214,11 +232,13 @@ class Rendezvous(object):
                     r, w, nonce = _HELLO.unpack(_recv_frame(c, self.key, _K_HELLO, _HELLO.size))
                     if w != self.world or not (1 <= r < self.world) or r in got:
                         raise ValueError("not a rank of this run")
-                    _send_frame(c, self.key, _K_WELCOME, _WELCOME.pack(self.world, nonce, os.urandom(16)))
+                    mine = os.urandom(16)
+                    _send_frame(c, self.key, _K_WELCOME, _WELCOME.pack(self.world, nonce, mine))
                 except (OSError, ValueError, struct.error):
                     c.close()  # (somebody else's connection)
                     continue
                 c.settimeout(self.io_timeout)
+                self._keys[c] = hmac.new(self.key, b"conn" + nonce + mine, hashlib.sha256).digest()
                 got[r] = c
             srv.close()
             self.peers = [got[r] for r in range(1, self.world)]
@@ -239,9 +259,10 @@ class Rendezvous(object):
                         c.settimeout(5.0)
                         nonce = os.urandom(16)
                         _send_frame(c, self.key, _K_HELLO, _HELLO.pack(self.rank, self.world, nonce))
-                        w, back, _ = _WELCOME.unpack(_recv_frame(c, self.key, _K_WELCOME, _WELCOME.size))
+                        w, back, theirs = _WELCOME.unpack(_recv_frame(c, self.key, _K_WELCOME, _WELCOME.size))
                         if w == self.world and back == nonce:
                             s, self.port = c, pt
+                            self._keys[c] = hmac.new(self.key, b"conn" + nonce + theirs, hashlib.sha256).digest()
                             break
                         c.close()
                     except (OSError, ValueError, struct.error):
@@ -261,11 +282,11 @@ class Rendezvous(object):
     def _send(self, sock, obj):
         out = []
         _enc(obj, out)
-        _send_frame(sock, self.key, _K_DATA, b"".join(out))
+        _send_frame(sock, self._keys.get(sock, self.key), _K_DATA, b"".join(out))
 
     def _recv(self, sock):
         try:
-            payload = _recv_frame(sock, self.key, _K_DATA, None)
+            payload = _recv_frame(sock, self._keys.get(sock, self.key), _K_DATA, self.max_frame)
         except socket.timeout:
             raise TimeoutError("rendezvous: a peer sent nothing for %.0f s (a rank died?)" % self.io_timeout)
         obj, at = _dec(memoryview(payload), 0)
@@ -307,6 +328,7 @@ class Rendezvous(object):
         if self.sock is not None:
             self.sock.close()
         self.peers, self.sock = [], None
+        self._keys = {}
 
 
 class RankPlanner(object):
@@ -353,6 +375,7 @@ class RankPlanner(object):
                 self.engine = Planner([device])
                 self.host_broadcast = True
         self.shape = None
+        self._shard = (0, 0)
 
     def set_grid(self, occ=None):
         """Rank 0 passes the uint8 [W][H] occupancy; every rank ends up with it resident."""
@@ -383,6 +406,49 @@ class RankPlanner(object):
         goals = np.asarray(goals, dtype=np.int32).reshape(-1, 2)
         lo, hi = shard_bounds(len(starts), self.rank, self.world)
         return (lo, hi) + tuple(self.engine.plan_batch(starts[lo:hi], goals[lo:hi], hchoice, max_path_len))
+
+    # -- streaming replans across ranks (BASELINE config 5; global_planner_ccst.py:476-480): only the cell updates travel
+    def _bcast_cells(self, xy, val):
+        if self.rank == 0:
+            if xy is None:
+                xy, val = np.zeros((0, 2), np.int32), np.zeros(0, np.uint8)
+            xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+            val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1)
+            if len(xy) != len(val):
+                raise ValueError("xy and val lengths differ")
+        xy, val = self.rdv.bcast((xy, val) if self.rank == 0 else None)
+        return xy, val
+
+    def update_cells(self, xy=None, val=None, rebuild=True):
+        """Rank 0 passes the cell updates (xy int32[n, 2], val uint8[n]); EVERY rank applies them to its resident grid and
+        rebuilds what they can reach (the toggle list travels -- ~ 420 KB for a config-5 frame --, never the
+        grid).  Collective: every rank calls it."""
+        xy, val = self._bcast_cells(xy, val)
+        self.engine.update_cells(xy, val, rebuild)
+        return len(val)
+
+    def set_queries(self, starts, goals, hchoice=2, max_path_len=None):
+        """The persistent (start, goal) set of the streaming replans: every rank keeps its contiguous shard."""
+        starts = np.asarray(starts, dtype=np.int32).reshape(-1, 2)
+        goals = np.asarray(goals, dtype=np.int32).reshape(-1, 2)
+        lo, hi = shard_bounds(len(starts), self.rank, self.world)
+        self._shard = (lo, hi)
+        self.engine.set_queries(starts[lo:hi], goals[lo:hi], hchoice, max_path_len)
+        return lo, hi
+
+    def replan_frame(self, xy=None, val=None):
+        """One frame on every rank: rank 0's cell updates reach all ranks, each applies them, rebuilds its maps and plans its
+        shard of the stored queries.  -> (lo, hi, offsets, cells, cost, status) of this rank's shard; `gather` merges them
+        into exactly what one GPU's fxjps_replan_frame returns.  Collective: every rank calls it."""
+        xy, val = self._bcast_cells(xy, val)
+        lo, hi = self._shard
+        return (lo, hi) + tuple(self.engine.replan_frame(xy, val))
+
+    def grid_hashes(self):
+        """SHA-256 of the grid every rank holds resident, in rank order, on every rank (equal on every rank
+        after the broadcast, and after every frame of cell updates)."""
+        h = hashlib.sha256(np.ascontiguousarray(self.engine.get_grid()).tobytes()).hexdigest()
+        return self.rdv.bcast(self.rdv.gather(h))
 
     def gather(self, off, cells, cost, status):
         """rank 0: the merged CSR result in query order; the others: None"""

@@ -36,6 +36,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the functions declared between this push and the pop at the end of the
+ * header are its whole dynamic symbol table (tests/test_host_cpu.py checks `nm -D` against this list, both ways). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 typedef struct fxjps fxjps_t;
 
 /* library-level return codes */
@@ -65,8 +71,11 @@ typedef struct fxjps fxjps_t;
  *   500  round 5: the version says so now; fxjps_timing_size() / fxjps_last_timing_sized() for hosts that want to be safe
  *        against the next growth; the whole-grid setters refuse handles of fxjps_create_rank with world > 1;
  *        fxjps_rank_preflight, fxjps_reserve_grid.
+ *   600  round 6: fxjps_get_grid_context (the resident grid of ONE context of a multi-device handle: what a host compares
+ *        after the broadcast); the library exports nothing but the functions of this header (-fvisibility=hidden + an
+ *        export map); the text of a failed fxjps_create* is kept per calling thread.
  * fxjps_timing_t only ever grows at its end. */
-#define FXJPS_VERSION 500
+#define FXJPS_VERSION 600
 int fxjps_version(void);
 
 /* Number of HIP devices visible, or a negative code. */
@@ -135,6 +144,9 @@ int fxjps_prepare_occupancy_msg(fxjps_t* h, const int8_t* data, int32_t width, i
 
 /* Copy the resident grid back (out may be NULL to query the size only). */
 int fxjps_get_grid(fxjps_t* h, uint8_t* out, int32_t* out_W, int32_t* out_H);
+/* The same for context `ctx` of a multi-device handle (0 .. contexts - 1, fxjps_comm_info): the bytes THAT device holds
+ * after the broadcast of fxjps_set_grid -- SURVEY.md 4 T4 asks for the grid hash to be equal on every device. */
+int fxjps_get_grid_context(fxjps_t* h, int32_t ctx, uint8_t* out, int32_t* out_W, int32_t* out_H);
 
 /* ---- Wire / on-disk adapters; device-side byte transposes of the resident grid.
  *
@@ -355,6 +367,10 @@ int fxjps_waypoint_st_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, cons
                             const double* origin, const double* pos, const double* goal, const int32_t* end_occu, double dis_wp_tre,
                             double ang_wp_tre, const double* prev_wp, const int32_t* prev_dim, double* out_wp, int32_t* out_dim,
                             double* out_goal, double* out_ang_wp, int32_t nthreads);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -809,7 +809,8 @@ import numpy as np
 import torch.distributed as dist
 import fuxi_planner_amd as fx
 from fuxi_planner_amd import synth
-from fuxi_planner_amd.distributed import ShardedPlanner
+sys.path.insert(0, os.path.join(%(root)r, "tools"))
+from torch_group import ShardedPlanner  # (the torch.distributed wrapper is a tool, not part of the package)
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank = dist.get_rank()
 planner = fx.Planner([0])                      # the real HIP planner; both ranks share GPU 0 on a 1-GPU box

@@ -15,10 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def libpath():
     from fuxi_planner_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        sys.path.insert(0, ROOT)
-        import __graft_entry__
-        __graft_entry__.build()
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()  # (`make`: nothing to do when the library is newer than its sources; rebuilds a stale one)
     return _lib.LIB_PATH
 
 
@@ -31,7 +30,12 @@ def test_library_exports_every_declared_symbol(libpath):
         assert hasattr(L, name), "libfxjps.so does not export %s" % name
     from fuxi_planner_amd import _lib
     assert declared == set(_lib.SYMBOLS)
-    assert L.fxjps_version() >= 100
+    assert L.fxjps_version() == _lib.VERSION
+    # ... and nothing else: no kernel handle, no device stub, no helper with a generic name, no template instantiation of
+    # the C++ library (-fvisibility=hidden + csrc/exports.map)
+    nm = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if l.strip()}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def _have_gpu(libpath):
@@ -89,7 +93,8 @@ import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np
 import torch.distributed as dist
-from fuxi_planner_amd.distributed import ShardedPlanner
+sys.path.insert(0, os.path.join(%(root)r, "tools"))
+from torch_group import ShardedPlanner  # (the torch.distributed wrapper is a tool, not part of the package)
 from oracle import oracle
 
 class CheckerEngine(object):
@@ -155,6 +160,17 @@ class CheckerEngine(object):
         off = np.zeros(len(ln) + 1, dtype=np.int64); off[1:] = np.cumsum(np.maximum(ln, 0))
         flat = np.concatenate([cells[q, :max(ln[q], 0)] for q in range(len(ln))] or [np.zeros((0, 2), np.int32)])
         return off, flat, cost, ln
+    # the streaming surface of Planner (fxjps_update_cells / fxjps_set_queries / fxjps_replan_frame / fxjps_get_grid)
+    def update_cells(self, xy, val, rebuild=True):
+        if len(val):
+            self.occ[xy[:, 0], xy[:, 1]] = val
+    def set_queries(self, starts, goals, hchoice=2, max_path_len=None):
+        self.q = (np.array(starts), np.array(goals), hchoice, max_path_len)
+    def replan_frame(self, xy, val):
+        self.update_cells(xy, val)
+        return self.plan_batch(*self.q)
+    def get_grid(self):
+        return self.occ
 
 rdv = Rendezvous.from_env()
 rank, world = rdv.rank, rdv.world
@@ -173,6 +189,35 @@ if rank == 0:
     print("MERGED-OK")
 else:
     assert merged is None
+# ---- streaming replans across the ranks: rank 0's cell updates reach every rank, every rank plans its shard of the stored queries
+hs = rp.grid_hashes()
+assert len(hs) == world and len(set(hs)) == 1, hs
+assert rp.set_queries(s, g, 2, 256) == (lo, hi)
+grid_now = full.copy()
+rng = np.random.default_rng(3)
+for fr in range(3):
+    xy = np.stack([rng.integers(0, 80, 200), rng.integers(0, 120, 200)], 1).astype(np.int32)
+    val = rng.integers(0, 2, 200).astype(np.uint8)
+    keep = np.ones(200, bool)                       # (never on a query endpoint, as SURVEY 8d's toggle stream)
+    for arr in (s, g):
+        keep &= ~((xy[:, None, :] == arr[None, :, :]).all(2).any(1))
+    xy, val = xy[keep], val[keep]
+    grid_now[xy[:, 0], xy[:, 1]] = val              # (every rank draws the same list; only rank 0 passes it on)
+    flo, fhi, off, cells, cost, status = rp.replan_frame(xy if rank == 0 else None, val if rank == 0 else None)
+    assert (flo, fhi) == (lo, hi)
+    assert np.array_equal(rp.engine.occ, grid_now)  # the updates arrived on this rank
+    merged = rp.gather(off, cells, cost, status)
+    hs = rp.grid_hashes()
+    assert len(set(hs)) == 1, hs
+    if rank == 0:
+        c1, l1, k1, _ = oracle.plan_batch(grid_now, s, g, 2, max_len=256)
+        assert np.array_equal(merged[3], l1) and merged[2].tobytes() == k1.tobytes()
+        for q in range(100):
+            assert np.array_equal(merged[1][merged[0][q]:merged[0][q + 1]], c1[q, :max(l1[q], 0)])
+n = rp.update_cells(np.array([[1, 1]], np.int32) if rank == 0 else None, np.array([1], np.uint8) if rank == 0 else None)
+assert n == 1 and rp.engine.occ[1, 1] == 1
+if rank == 0:
+    print("FRAMES-OK")
 rdv.barrier()
 m = rdv.max([float(rank), 10.0 - rank])
 assert m == [float(world - 1), 10.0], m
@@ -193,7 +238,7 @@ def test_three_ranks_without_torch(tmp_path, oracle):
                               stderr=subprocess.STDOUT, text=True) for r in range(3)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    assert "MERGED-OK" in outs[0]
+    assert "MERGED-OK" in outs[0] and "FRAMES-OK" in outs[0]
     assert "RANK 0 0 33" in outs[0] and "RANK 1 33 66" in outs[1] and "RANK 2 66 100" in outs[2]
 
 

@@ -56,6 +56,11 @@ for nq in nqs:
     if c[4] and c[51]:
         print("   second rounds in %.1f %% of the batches: %.2f more nodes each; intruder on a diagonal ray %.1f %%; predictable before the table lines: unique candidate in %.1f %% of the batches, with known cell info %.1f %%, and right in %.1f %% of the second rounds" % (
             100.0 * c[51] / c[4], c[52] / c[51], 100.0 * c[53] / c[51], 100.0 * c[54] / c[4], 100.0 * c[55] / c[4], 100.0 * c[56] / c[51]), flush=True)
+    if c[4] and c[50]:
+        print("   open list per batch: %.2f pushes merged into R (r_merge ran in %.1f %% of the batches), %.2f appended to M, %.2f to the far tier" % (
+            c[32] / c[4], 100.0 * c[50] / c[4], c[40] / c[4], c[41] / c[4]), flush=True)
+        print("   loop trips per batch: rays with a key inside the batch %.2f; per second round: cells of s checked %.2f, pushes of s inside the batch %.2f" % (
+            c[42] / c[4], c[48] / max(c[51], 1), c[49] / max(c[51], 1)), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)
