@@ -362,15 +362,24 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
             // ... and which of those cells changed: where the re-scan of the jump distances starts (k_jd_walk)
             const bool walk = !(getenv("FXJPS_JD_WALK") && atoi(getenv("FXJPS_JD_WALK")) == 0);  // (0: measurement / test aid -- every record is read)
             if (walk) {
+                // The change list is an optimisation with buffers of its own (up to 4 bytes per cell of the cross: 67 MB for
+                // a half-map box at 4096^2): when the device has no room for them -- pool 0 of a lone handle may hold 80 % of
+                // it -- the update does not fail, it takes round 4's way (every word of the diagonals through the cross
+                // rebuilt, every record read: chg.map stays nullptr).
+                bool room = true;
                 if (!d.chg_ready) {  // (streaming callers only: with the first partial rebuild on a grid)
-                    HIPCHK(h, d.d_chgmap.ensure((size_t)d.PW * d.NS));
-                    HIPCHK(h, d.d_chgcnt.ensure(4));
-                    HIPCHK(h, hipMemsetAsync(d.d_chgmap.p, 0, (size_t)d.PW * d.NS, d.stream));
-                    HIPCHK(h, hipMemsetAsync(d.d_chgcnt.p, 0, 4 * sizeof(unsigned int), d.stream));
-                    d.chg_ready = true;
+                    room = d.d_chgmap.ensure((size_t)d.PW * d.NS) == hipSuccess && d.d_chgcnt.ensure(4) == hipSuccess;
+                    if (room) {
+                        HIPCHK(h, hipMemsetAsync(d.d_chgmap.p, 0, (size_t)d.PW * d.NS, d.stream));
+                        HIPCHK(h, hipMemsetAsync(d.d_chgcnt.p, 0, 4 * sizeof(unsigned int), d.stream));
+                        d.chg_ready = true;
+                    }
                 }
-                HIPCHK(h, d.d_chglist.ensure((size_t)(na + nb)));
-                chg = fx::ChangeOut{d.d_chgmap.p, d.d_chglist.p, d.d_chgcnt.p, (uint32_t)(na + nb), fx::MapRange{d.bx0, d.bx1, d.by0, d.by1}};
+                room = room && d.d_chglist.ensure((size_t)(na + nb)) == hipSuccess;
+                if (room)
+                    chg = fx::ChangeOut{d.d_chgmap.p, d.d_chglist.p, d.d_chgcnt.p, (uint32_t)(na + nb), fx::MapRange{d.bx0, d.bx1, d.by0, d.by1}};
+                else
+                    (void)hipGetLastError();  // (the failed allocation's sticky error: not this update's business)
             }
             hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa, sb, chg);
         } else {
@@ -895,6 +904,28 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
         d.nrun = head[KMAX + 2u];
         for (int64_t i = 0; i < nq; i++)
             if (in(i)) d.h_order[head[KMAX - key(i)]++] = (uint32_t)i;
+        // Measurement aid (round 6, DESIGN.md section 4: no gain, off): within classes of 128 key values the queries in Morton
+        // order of the middle of start and goal, so that wavefronts that start together read neighbouring lines of the maps.
+        // The order is not an output: results are the same bytes either way.
+        static const bool morton = getenv("FXJPS_ORDER_MORTON") && atoi(getenv("FXJPS_ORDER_MORTON")) != 0;
+        if (morton && d.nrun > 1) {
+            auto spread = [](uint32_t v) -> uint64_t {  // bits of v to the even positions
+                uint64_t x = v & 0xFFFFu;
+                x = (x | (x << 8)) & 0x00FF00FFull;
+                x = (x | (x << 4)) & 0x0F0F0F0Full;
+                x = (x | (x << 2)) & 0x33333333ull;
+                x = (x | (x << 1)) & 0x55555555ull;
+                return x;
+            };
+            std::vector<std::pair<uint64_t, uint32_t>> ks((size_t)d.nrun);
+            for (int64_t j = 0; j < d.nrun; j++) {
+                const int64_t i = d.h_order[(size_t)j];
+                const uint32_t mx = (uint32_t)((S[2 * i] + G[2 * i]) / 2), my = (uint32_t)((S[2 * i + 1] + G[2 * i + 1]) / 2);
+                ks[(size_t)j] = {((uint64_t)((KMAX - key(i)) >> 7) << 32) | (spread(mx >> 3) << 1) | spread(my >> 3), (uint32_t)i};
+            }
+            std::sort(ks.begin(), ks.end());
+            for (int64_t j = 0; j < d.nrun; j++) d.h_order[(size_t)j] = ks[(size_t)j].second;
+        }
         HIPCHK(h, d.d_order.ensure((size_t)nq));
         if (d.nrun > 0)
             HIPCHK(h, hipMemcpyAsync(d.d_order.p, d.h_order.data(), (size_t)d.nrun * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
@@ -1863,7 +1894,15 @@ int update_cells_async(fxjps_t* h, const int32_t* xy, const uint8_t* val, int64_
         }
         if (derive) {
             int rc = derive_maps(h, d, !partial);
-            if (rc) return rc;
+            if (rc) {
+                // The cells and the labels are already changed on the device (k_update_cells, k_ccl_update are queued), the
+                // maps are not: whoever plans next must rebuild them (maps_stale), and the staging buffers stay taken until
+                // what was queued has passed (ev_upd) -- the next update would otherwise overwrite a copy still in flight.
+                h->maps_stale = true;
+                d.dirty = true;
+                if (n > 0 && hipEventRecord(d.ev_upd, d.stream) == hipSuccess) d.upd_pending = true;
+                return rc;
+            }
         }
         if (n > 0) {  // the list's last readers are queued: the staging buffers are free again once this event has passed
             HIPCHK(h, hipEventRecord(d.ev_upd, d.stream));

@@ -44,7 +44,7 @@ for nq in nqs:
     if c[4]:
         print("   nodes of a batch not committed: %.2f key rule or shared bucket, %.2f goal/parent/full bucket" % (c[24] / c[4], c[25] / c[4]), flush=True)
     if c[4] and c[33]:
-        print("   lanes in use %.1f / batch, nodes without lanes %.2f / batch, behind a shared bucket %.2f / batch, key-rule count ran in %.1f %% of the batches" % (
+        print("   lanes in use %.1f / batch, nodes without lanes %.2f / batch, behind a shared bucket %.2f / batch, (unused %.1f)" % (
             c[33] / c[4], c[34] / c[4], c[31] / c[4], 100.0 * c[32] / c[4]), flush=True)
     if c[4] and c[35]:
         print("   rays held back by the bucket detector %.3f / batch (in %.1f %% of the batches): %.1f %% really share a bucket, %.1f %% relaxed as the second of a pair; batches cut %.1f %%" % (
@@ -58,9 +58,9 @@ for nq in nqs:
             100.0 * c[51] / c[4], c[52] / c[51], 100.0 * c[53] / c[51], 100.0 * c[54] / c[4], 100.0 * c[55] / c[4], 100.0 * c[56] / c[51]), flush=True)
     if c[4] and c[50]:
         print("   open list per batch: %.2f pushes merged into R (r_merge ran in %.1f %% of the batches), %.2f appended to M, %.2f to the far tier" % (
-            c[32] / c[4], 100.0 * c[50] / c[4], c[40] / c[4], c[41] / c[4]), flush=True)
-        print("   loop trips per batch: rays with a key inside the batch %.2f; per second round: cells of s checked %.2f, pushes of s inside the batch %.2f" % (
-            c[42] / c[4], c[48] / max(c[51], 1), c[49] / max(c[51], 1)), flush=True)
+            c[32] / c[4], 100.0 * c[50] / c[4], c[58] / c[4], (c[1] - c[32] - c[58]) / c[4]), flush=True)
+        print("   loop trips per batch: rays with a key inside the batch %.2f; per second round: cells of s checked %.2f (sieve let %.1f %% of the second rounds through), pushes of s inside the batch %.2f" % (
+            c[59] / c[4], c[48] / max(c[51], 1), 100.0 * c[57] / max(c[51], 1), c[49] / max(c[51], 1)), flush=True)
     tot = sum(c[8:18])
     if tot:
         print("   cycles/pop %.0f : " % (tot / max(c[0], 1)) + ", ".join("%s %.0f (%.0f%%)" % (names[k], c[8 + k] / max(c[0], 1), 100.0 * c[8 + k] / tot) for k in range(10)), flush=True)

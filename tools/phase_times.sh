@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 if [ "$MODE" = build ]; then
   n=0
   for iv in $IV; do s=${iv%%:*}; e=${iv#*:}
-    ( cd fuxi-planner_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -shared -DFXJPS_PHASE_S=$s -DFXJPS_PHASE_E=$e -o libfxjps_ph_${s}_${e}.so csrc/fxjps_waypoints.o csrc/fxjps.hip -ldl 2>&1 | grep -E "error" ) &
+    ( cd fuxi-planner_amd && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -shared -fvisibility=hidden $FX_PHASE_FLAGS -DFXJPS_PHASE_S=$s -DFXJPS_PHASE_E=$e -o libfxjps_ph_${s}_${e}.so csrc/fxjps_waypoints.o csrc/fxjps.hip -Wl,--version-script=csrc/exports.map -ldl 2>&1 | grep -E "error" ) &
     n=$((n+1)); if [ $((n % 4)) -eq 0 ]; then wait; fi
   done; wait; ls fuxi-planner_amd/libfxjps_ph_*.so
 else
