@@ -209,6 +209,10 @@ struct DevCtx {
     // that they need not outlive the call (ev_upd: the last copy out of the staging buffers has completed)
     HBuf<int32_t> h_upd_xy;
     hipEvent_t ev_upd = nullptr;
+    HBuf<uint8_t> h_occ_stage;      // a small grid on its way to the device (fxjps_set_grid returns while it travels)
+    hipEvent_t ev_stage = nullptr;  // ... the copy out of it has completed
+    bool stage_pending = false;
+    hipEvent_t ev_ccl0 = nullptr, ev_ccl1 = nullptr;  // a whole map build: the component labels on the second stream, beside the maps
     bool upd_pending = false;
     HBuf<int32_t> h_len, h_cells;
     HBuf<uint32_t> h_path1;       // single calls: the search kernel writes the packed path of its one query here
@@ -346,6 +350,41 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
     if (!whole && !d.dirty && !d.ccl_full) return FXJPS_OK;
     const bool box = !whole && d.dirty && (d.bx1 - d.bx0 + 1) * 2 <= d.PW && (d.by1 - d.by0 + 1) * 2 <= d.PH;
     const GridDev G = grid_of(d);
+    // A whole build (a new grid): the component labels need nothing but the occupancy bytes, the five map kernels nothing of
+    // the labels -- the three label kernels run on the handle's second stream beside them and join in front of whatever is
+    // queued next (round 6: 27 of the 76 us of a 256 x 256 build; 221 of 382 us at 1024 x 1024).
+    // A small grid: four launches instead of eight (k_build_1 .. 3, then k_derive_jd): what a build of tiny kernels waits for
+    // is the runtime launching them one by one.  FXJPS_FUSED_BUILD=0: the separate kernels (test / measurement aid).
+    const char* fused_env = getenv("FXJPS_FUSED_BUILD");  // (read per build: the tests compare the two forms in one process)
+    if (whole && !(fused_env && atoi(fused_env) == 0) && (long long)d.W * d.H <= (1ll << 18)) {
+        const long long ncell = (long long)d.W * d.H, npad = (long long)d.PW * d.PH;
+        const unsigned nb_rows = (unsigned)(((long long)d.PW * d.WORDS + 3) / 4), nb_cols = (unsigned)(((long long)d.PH * d.WORDS + 3) / 4);
+        const unsigned nb_cell = (unsigned)((ncell + 255) / 256), nb_ci = (unsigned)((npad + 255) / 256);
+        const unsigned nb_diag = (unsigned)((4ll * G.DLINES * d.WORDS + 15) / 16), nb_flat = (unsigned)((ncell + 1023) / 1024);
+        hipLaunchKernelGGL(fx::k_build_1, dim3(nb_rows + nb_cols + nb_cell), dim3(256), 0, d.stream, d.occ.p, G, d.nb8.p, d.bm.p, d.comp.p, nb_rows, nb_cols);
+        hipLaunchKernelGGL(fx::k_build_2, dim3(nb_ci + nb_cell), dim3(256), 0, d.stream, d.occ.p, G, d.ci.p, d.comp.p, nb_ci);
+        hipLaunchKernelGGL(fx::k_build_3, dim3(nb_diag + nb_flat), dim3(1024), 0, d.stream, d.occ.p, G, d.bm.p + (size_t)4 * d.LINES * d.WORDS, d.comp.p, nb_diag);
+        hipLaunchKernelGGL(fx::k_derive_jd, dim3((unsigned)((npad * 8 + 255) / 256)), dim3(256), 0, d.stream, G, d.jd.p, fx::DiagRange{1, d.bx0, d.bx1, d.by0, d.by1});
+        HIPCHK(h, hipGetLastError());
+        d.ccl_small = 0;
+        d.dirty = false;
+        d.ccl_full = false;
+        return FXJPS_OK;
+    }
+    const bool ccl_beside = whole && d.stream_solo != nullptr && d.ev_ccl0 != nullptr;
+    const auto launch_ccl = [&](hipStream_t st) {
+        const long long n = (long long)d.W * d.H;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(fx::k_ccl_init, dim3(nb), dim3(256), 0, st, d.occ.p, n, d.H, d.comp.p);
+        hipLaunchKernelGGL(fx::k_ccl_merge, dim3(nb), dim3(256), 0, st, d.occ.p, d.W, d.H, d.comp.p);
+        hipLaunchKernelGGL(fx::k_ccl_flatten, dim3(nb), dim3(256), 0, st, n, d.comp.p);
+    };
+    if (ccl_beside) {
+        HIPCHK(h, hipEventRecord(d.ev_ccl0, d.stream));  // (behind the copy / broadcast that brought the grid)
+        HIPCHK(h, hipStreamWaitEvent(d.stream_solo, d.ev_ccl0, 0));
+        launch_ccl(d.stream_solo);
+        HIPCHK(h, hipEventRecord(d.ev_ccl1, d.stream_solo));
+    }
     if (whole || d.dirty) {
         fx::MapRange rr{0, d.PW - 1, 0, d.WORDS - 1}, rc{0, d.PH - 1, 0, d.WORDS - 1};
         if (box) {
@@ -395,7 +434,7 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
                 hipLaunchKernelGGL(fx::k_diag_update, dim3((unsigned)std::min<long long>(((long long)chg.cap * 4 + 255) / 256, 256)), dim3(256), 0, d.stream,
                                    d.occ.p, G, d.bm.p + (size_t)4 * d.LINES * d.WORDS, chg);
             else
-                hipLaunchKernelGGL(fx::k_derive_diag, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, d.stream, d.occ.p, G,
+                hipLaunchKernelGGL(fx::k_derive_diag, dim3((unsigned)((nw + 15) / 16)), dim3(1024), 0, d.stream, d.occ.p, G,
                                    d.bm.p + (size_t)4 * d.LINES * d.WORDS, dr);
             // ... and the jump distances: the goal-free jumps themselves, from every cell along every direction, read off
             // the scan words above (after an update: the entries whose old ray passes what the update can have changed)
@@ -416,13 +455,13 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
         }
         HIPCHK(h, hipGetLastError());
     }
-    if (whole || d.ccl_full) {
+    if (ccl_beside) {
+        HIPCHK(h, hipStreamWaitEvent(d.stream, d.ev_ccl1, 0));  // the join: whatever is queued on the main stream next sees the labels
+        HIPCHK(h, hipGetLastError());
+        d.ccl_small = 0;
+    } else if (whole || d.ccl_full) {
         // component labels for the unreachable-goal early-out
-        const long long n = (long long)d.W * d.H;
-        const unsigned nb = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(fx::k_ccl_init, dim3(nb), dim3(256), 0, d.stream, d.occ.p, n, d.comp.p);
-        hipLaunchKernelGGL(fx::k_ccl_merge, dim3(nb), dim3(256), 0, d.stream, d.occ.p, d.W, d.H, d.comp.p);
-        hipLaunchKernelGGL(fx::k_ccl_flatten, dim3(nb), dim3(256), 0, d.stream, n, d.comp.p);
+        launch_ccl(d.stream);
         HIPCHK(h, hipGetLastError());
         d.ccl_small = 0;
     }
@@ -1075,7 +1114,11 @@ int plan_single(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals
     A.out_len = (int32_t*)dp_len;
     A.out_cost = (double*)dp_cost;
     d.h_len.p[0] = fx::QI_WATCHDOG;  // (overwritten by the kernel)
-    HIPCHK(h, hipMemsetAsync(d.d_counters.p, 0, 64 * sizeof(unsigned long long), d.stream));
+    // (round 6: the kernel zeroes its 64 counters itself and leaves them in the pinned host buffer when it is done -- a memset
+    // and a copy back were two more operations for the runtime to queue, ~ 12 us of a call)
+    void* dp_cnt = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer(&dp_cnt, d.h_counters.p, 0));
+    A.host_counters = (unsigned long long*)dp_cnt;
     HIPCHK(h, hipEventRecord(d.ev0, d.stream));
     {
         using KFn = void (*)(SearchArgs);
@@ -1085,7 +1128,6 @@ int plan_single(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipEventRecord(d.ev1, d.stream));
-    HIPCHK(h, hipMemcpyAsync(d.h_counters.p, d.d_counters.p, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(h, hipStreamSynchronize(d.stream));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
@@ -1289,7 +1331,7 @@ int refuse_on_rank_handle(fxjps* h, const char* what) {
     return FXJPS_OK;
 }
 
-int finish_set_grid(fxjps* h, int W, int H) {
+int finish_set_grid(fxjps* h, int W, int H, bool wait = true) {
     int rc = broadcast_grid(h, W, H);
     if (rc) return rc;
     for (auto& d : h->devs) {
@@ -1297,6 +1339,7 @@ int finish_set_grid(fxjps* h, int W, int H) {
         if (rc) return rc;
     }
     for (auto& d : h->devs) {
+        if (!wait) break;  // (one context, a small grid out of a staging buffer: whatever is queued next runs behind the build)
         HIPCHK(h, hipSetDevice(d.dev));
         HIPCHK(h, hipStreamSynchronize(d.stream));
     }
@@ -1384,6 +1427,9 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         if (e == hipSuccess) e = hipEventCreate(&d.ev_bt0);
         if (e == hipSuccess) e = hipEventCreate(&d.ev_bt1);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_upd, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_stage, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_ccl0, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d.ev_ccl1, hipEventDisableTiming);
         if (e != hipSuccess) {
             int rc = fail(nullptr, FXJPS_E_HIP, "device %d: %s", d.dev, hipGetErrorString(e));
             fxjps_destroy(h);
@@ -1565,6 +1611,10 @@ void fxjps_destroy(fxjps_t* h) {
         d.h_upd_xy.release();
         d.h_path1.release();
         if (d.ev_upd) (void)hipEventDestroy(d.ev_upd);
+        if (d.ev_stage) (void)hipEventDestroy(d.ev_stage);
+        d.h_occ_stage.release();
+        if (d.ev_ccl0) (void)hipEventDestroy(d.ev_ccl0);
+        if (d.ev_ccl1) (void)hipEventDestroy(d.ev_ccl1);
         if (d.solo_started) (void)hipHostFree(d.solo_started);
         if (d.ev_solo0) (void)hipEventDestroy(d.ev_solo0);
         if (d.ev_solo1) (void)hipEventDestroy(d.ev_solo1);
@@ -1593,7 +1643,24 @@ int fxjps_set_grid(fxjps_t* h, const uint8_t* occ, int32_t W, int32_t H) {
     }
     DevCtx& d0 = h->devs[0];
     HIPCHK(h, hipSetDevice(d0.dev));
-    HIPCHK(h, hipMemcpyAsync(d0.occ.p, occ, (size_t)W * H, hipMemcpyHostToDevice, d0.stream));
+    // The node's call (jps1.method once per tick on a map of ~ 150 x 110 cells): a small grid on a one-context handle goes
+    // through a pinned staging buffer of the handle, and the call returns as soon as the copy and the map build are QUEUED --
+    // the search of the same tick is queued right behind them, no host wait in between (round 6: 437 -> ~ 300 us for a tick
+    // whose map changed; the caller's buffer is its own again when the call returns, as the ABI promises).  An error of the
+    // build itself would surface at the next call that waits.  FXJPS_SETGRID_WAIT=1: wait as before (test / measurement aid).
+    static const bool always_wait = getenv("FXJPS_SETGRID_WAIT") && atoi(getenv("FXJPS_SETGRID_WAIT")) != 0;
+    const size_t bytes = (size_t)W * H;
+    if (h->devs.size() == 1 && bytes <= ((size_t)1 << 18) && !always_wait && d0.ev_stage != nullptr) {
+        if (d0.stage_pending) HIPCHK(h, hipEventSynchronize(d0.ev_stage));  // (the previous grid has left the buffer)
+        d0.stage_pending = false;
+        HIPCHK(h, d0.h_occ_stage.ensure(bytes));
+        memcpy(d0.h_occ_stage.p, occ, bytes);
+        HIPCHK(h, hipMemcpyAsync(d0.occ.p, d0.h_occ_stage.p, bytes, hipMemcpyHostToDevice, d0.stream));
+        HIPCHK(h, hipEventRecord(d0.ev_stage, d0.stream));
+        d0.stage_pending = true;
+        return finish_set_grid(h, W, H, false);
+    }
+    HIPCHK(h, hipMemcpyAsync(d0.occ.p, occ, bytes, hipMemcpyHostToDevice, d0.stream));
     // (several contexts: the others copy from the first one's buffer on streams of their own.  One context: the map build
     // is queued behind the copy on the same stream, and finish_set_grid waits for both -- one host wait per call)
     if (h->devs.size() > 1) HIPCHK(h, hipStreamSynchronize(d0.stream));

@@ -113,6 +113,47 @@ def test_partial_rebuild_equals_fresh_upload(oracle, jd_mode, monkeypatch):
         assert na <= nb
 
 
+def test_fused_build_equals_separate_kernels(monkeypatch):
+    """A small grid is built in four launches (k_build_1 .. 3 + k_derive_jd: kernels that need nothing of each other share
+    a launch, the neighbour byte of the column words is computed instead of read); FXJPS_FUSED_BUILD=0 runs the eight separate
+    kernels.  Neighbour bytes, straight and diagonal scan words, cell infos, jump distances byte for byte, and the same
+    components, on the reference's 35 maps, the 256 x 256 canvas of config 1 and random grids up to the 2^18 cells the merged
+    form takes -- built twice in a row each."""
+    import json
+    import fuxi_planner_amd as fx
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z = np.load(os.path.join(root, "tests", "golden", "maps_png.npz"))
+    with open(os.path.join(root, "tests", "golden", "maps_png.json")) as f:
+        recs = json.load(f)
+    grids = []
+    for nm in z.files:
+        W, H = [r for r in recs if r["map"] == nm and "canvas" not in r][0]["shape"]
+        grids.append(np.unpackbits(z[nm])[:W * H].reshape(W, H).astype(np.uint8))
+    canvas = np.zeros((256, 256), np.uint8)
+    canvas[:147, :112] = grids[[i for i, nm in enumerate(z.files) if nm == "-16.20-11.40_out.png"][0]]
+    grids.append(canvas)
+    rng = np.random.default_rng(9)
+    for W, H, dens in ((1, 1, 0.0), (3, 70, 0.3), (65, 64, 0.4), (512, 512, 0.2), (400, 655, 0.05), (2100, 124, 0.35), (300, 300, 0.0), (64, 4096, 1.0)):
+        grids.append((rng.random((W, H)) < dens).astype(np.uint8))
+    monkeypatch.setenv("FXJPS_SETGRID_WAIT", "1")
+    with fx.Planner([0]) as p, fx.Planner([0]) as q:
+        for g in grids:
+            for rep in range(2):
+                monkeypatch.delenv("FXJPS_FUSED_BUILD", raising=False)
+                p.set_grid_occ(g)
+                monkeypatch.setenv("FXJPS_FUSED_BUILD", "0")
+                q.set_grid_occ(g)
+                a, b = p.debug_maps(), q.debug_maps()
+                for k in ("nb8", "bm", "ci", "dbm", "jd"):
+                    assert np.array_equal(a[k], b[k]), (g.shape, k, int((a[k] != b[k]).sum()))
+                free = np.flatnonzero(g.ravel() == 0)
+                ra, rb = roots(a["comp"])[free], roots(b["comp"])[free]
+                assert (ra >= 0).all() and (rb >= 0).all()
+                pairs = np.unique(np.stack([rb, ra]), axis=1)  # the same partition of the free cells
+                assert pairs.shape[1] == len(np.unique(rb)) == len(np.unique(ra)), g.shape
+                assert ((roots(a["comp"]) < 0) == (g.ravel() != 0)).all()
+
+
 def test_window_update_on_a_large_map_is_cheap():
     """A 64 x 64 window re-observed on 4096 x 4096: the rebuild touches 66 lines, the rows / columns through them and the
     jump distances whose rays reach a changed cell (found from the changed cells backwards), not 16 M cells, their labels
