@@ -60,7 +60,7 @@ DEFAULT_STEPS = {"c5pipe": (600, 16), "c2pipe": (24, 6)}  # workload -> (steps, 
 
 def kernel_src_sha16():
     h = hashlib.sha256()
-    for n in ("fxjps_kernels.hip.inc", "fxjps.hip"):
+    for n in ("fxjps_kernels.hip.inc", "fxjps_maps.hip.inc", "fxjps.hip"):
         with open(os.path.join(ROOT, "fuxi-planner_amd", "csrc", n), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

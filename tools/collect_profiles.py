@@ -8,7 +8,7 @@ import csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 h = hashlib.sha256()
-for n in ("fxjps_kernels.hip.inc", "fxjps.hip"):
+for n in ("fxjps_kernels.hip.inc", "fxjps_maps.hip.inc", "fxjps.hip"):
     h.update(open(os.path.join(ROOT, "fuxi-planner_amd", "csrc", n), "rb").read())
 sha = h.hexdigest()[:16]
 wl = json.load(open(os.path.join(ROOT, "fuxi-planner_amd", "workloads.json")))
