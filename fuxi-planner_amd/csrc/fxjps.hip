@@ -506,6 +506,10 @@ int alloc_grid(fxjps* h, DevCtx& d, int W, int H) {
     return FXJPS_OK;
 }
 
+// wavefront counts are whole blocks of fx::WPB wavefronts (any block size: a measurement build runs ten per block)
+constexpr uint64_t wpb_down(uint64_t v) { return v / (uint64_t)fx::WPB * (uint64_t)fx::WPB; }
+constexpr uint64_t wpb_up(uint64_t v) { return wpb_down(v + (uint64_t)fx::WPB - 1u); }
+
 uint32_t ceil_log2(uint64_t v) {
     uint32_t l = 0;
     while ((1ull << l) < v) l++;
@@ -599,7 +603,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
         // the largest of its 100 000 queries inserts 2.42 M nodes, a shrunk table takes 2.75 M).  FXJPS_TABLE_SHRINK=0:
         // measurement aid.
         if (c.direct_ly == 0 && !getenv("FXJPS_TABLE_LOG2") && !(getenv("FXJPS_TABLE_SHRINK") && atoi(getenv("FXJPS_TABLE_SHRINK")) == 0)) {
-            const uint64_t want = std::max<uint64_t>((want_waves + 7u) & ~7u, (uint64_t)fx::WPB);
+            const uint64_t want = std::max<uint64_t>(wpb_up(want_waves), (uint64_t)fx::WPB);
             const double per_entry = (double)sizeof(TEnt) + (1.0 + 1.0 / 8) * sizeof(FarEnt) / 8.0;
             const ScratchCfg& have = d.cfg[0];
             if (have.nbuckets != 0u && have.direct_ly == 0u && have.nwaves >= want) {
@@ -630,11 +634,10 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
     c.far_cap = (c.far_cap + 7u) & ~7u;  // the u16 cell-info array behind the entries stays 16-byte granular
     const size_t per_wave = ((size_t)fx::BUCKET * c.nbuckets) * sizeof(TEnt) + (size_t)(c.far_cap + c.far_cap / 8) * sizeof(FarEnt);
     uint32_t maxw = (uint32_t)std::min<size_t>(budget / per_wave, 1u << 20);
-    constexpr uint32_t WPBm = (uint32_t)fx::WPB - 1u;  // wavefront counts are whole blocks
-    maxw &= ~WPBm;
+    maxw = (uint32_t)wpb_down(maxw);
     if (maxw < (uint32_t)fx::WPB) return fail(h, FXJPS_E_NOMEM, "grid %dx%d needs %zu bytes of scratch per wavefront", d.W, d.H, per_wave);
-    if (((c.nwaves + WPBm) & ~WPBm) > maxw) d.waves_short = true;
-    c.nwaves = std::max((uint32_t)fx::WPB, std::min((c.nwaves + WPBm) & ~WPBm, maxw));
+    if ((uint32_t)wpb_up(c.nwaves) > maxw) d.waves_short = true;
+    c.nwaves = std::max((uint32_t)fx::WPB, std::min((uint32_t)wpb_up(c.nwaves), maxw));
     ScratchCfg& cur = d.cfg[pool];
     const bool same = cur.nbuckets == c.nbuckets && cur.usable == c.usable && cur.direct_ly == c.direct_ly && cur.far_cap == c.far_cap && cur.nwaves >= c.nwaves;
     if (same && d.pool_clean[pool]) return FXJPS_OK;
@@ -653,7 +656,7 @@ int ensure_pool(fxjps* h, DevCtx& d, int pool, uint32_t want_waves) {
             d.far[pool].release();
             if (e != hipErrorOutOfMemory || c.nwaves <= (uint32_t)fx::WPB)
                 return fail(h, e == hipErrorOutOfMemory ? FXJPS_E_NOMEM : FXJPS_E_HIP, "scratch pool %d: %s", pool, hipGetErrorString(e));
-            c.nwaves = std::max((uint32_t)fx::WPB, (c.nwaves / 2u) & ~WPBm);
+            c.nwaves = std::max((uint32_t)fx::WPB, (uint32_t)wpb_down(c.nwaves / 2u));
             d.waves_short = true;
             DBG("pool %d: out of memory, retrying with %u wavefronts", pool, c.nwaves);
         }
@@ -713,7 +716,7 @@ void fill_search_args(const DevCtx& d, int pool, SearchArgs& A, const uint32_t* 
 
 int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const ScratchCfg& c, const uint32_t* d_order, uint32_t nrun, int hchoice, bool track) {
     uint32_t waves = std::min<uint32_t>(c.nwaves, (nrun + 0u));
-    waves = std::max<uint32_t>((uint32_t)fx::WPB, (waves + (uint32_t)fx::WPB - 1u) & ~((uint32_t)fx::WPB - 1u));
+    waves = std::max<uint32_t>((uint32_t)fx::WPB, (uint32_t)wpb_up(waves));
     waves = std::min<uint32_t>(waves, c.nwaves);
     // Wavefronts per CU.  A query is a chain of dependent pops, and a wavefront that shares its CU with fifteen others runs
     // that chain more slowly than one that has the CU to itself (config 2, the long diagonal queries: 0.69 us per pop among
@@ -736,7 +739,7 @@ int launch_search_args(fxjps* h, DevCtx& d, int pool, SearchArgs& A, const Scrat
         waves <= 2u * nsolo + (uint32_t)fx::WPB)
         nsolo = 0;
     nsolo = std::min<uint32_t>(nsolo, 512u) & ~(live_solo - 1u);
-    if (nsolo != 0u) waves = std::min<uint32_t>(waves, (c.nwaves - nsolo) & ~((uint32_t)fx::WPB - 1u));
+    if (nsolo != 0u) waves = std::min<uint32_t>(waves, (uint32_t)wpb_down(c.nwaves - nsolo));
 
     if (pool != 0 || nsolo != 0u || (uint64_t)nrun > (uint64_t)d.n_cu * live_main || d.share * h->mem_div > 1) live_main = 0u;
     // One query per BLOCK (k_search_coop: a searching wavefront and a stager that keeps the LDS tier of its open list in
@@ -918,8 +921,8 @@ int run_shard(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals, 
         HIPCHK(h, hipMemsetAsync(d.d_qstat.p, 0, (size_t)nq * 4 * sizeof(unsigned long long), d.stream));
     }
     uint32_t full = (uint32_t)d.n_cu * 4u * (uint32_t)fx::OCC / (uint32_t)(d.share * h->mem_div);  // every wavefront the chip can hold at once (this handle's share of them)
-    full = std::max<uint32_t>(full & ~((uint32_t)fx::WPB - 1u), (uint32_t)fx::WPB);
-    if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)std::max(fx::WPB, atoi(e)) & ~((uint32_t)fx::WPB - 1u);  // measurement aid
+    full = std::max<uint32_t>((uint32_t)wpb_down(full), (uint32_t)fx::WPB);
+    if (const char* e = getenv("FXJPS_WAVES")) full = (uint32_t)wpb_down((uint64_t)std::max(fx::WPB, atoi(e)));  // measurement aid
     // Longest-processing-time-first: the time a query takes grows with the start-goal distance, so far-apart queries are
     // handed out first and the short ones fill the tail.  The key is max(dx, dy) + min(dx, dy) / 2: on the config-2
     // workload it correlates 0.95 with the time a query takes and 0.95 with its expansions (Chebyshev distance: 0.91 /
