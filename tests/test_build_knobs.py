@@ -15,6 +15,7 @@ KNOBS = [
     ["-DFXJPS_KN=32"], ["-DFXJPS_KN=8"], ["-DFXJPS_XCC=1"], ["-DFXJPS_PROF"], ["-DFXJPS_PROF", "-DFXJPS_PROF_LIGHT"],
     ["-DFXJPS_PHASE_S=7", "-DFXJPS_PHASE_E=2"], ["-DFXJPS_MARK"], ["-DFXJPS_HWID"],
     ["-DFXJPS_SORT_BITONIC=0"], ["-DFXJPS_R2_HASH=0", "-DFXJPS_ONE_INSERT=0"], ["-DFXJPS_R2_REC=1", "-DFXJPS_RFILL_F32=1"],
+    ["-DFXJPS_OCC=5", "-DFXJPS_WPB=5", "-DFXJPS_PTR_SGPR=1", "-DFXJPS_HZ_LOG2=7"],
 ]
 
 
