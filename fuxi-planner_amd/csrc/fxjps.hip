@@ -197,6 +197,7 @@ struct DevCtx {
     DBuf<uint8_t> d_chgmap;
     DBuf<uint32_t> d_chglist;
     DBuf<unsigned int> d_chgcnt;
+    DBuf<uint32_t> d_chgovf;  // walks handed on to k_jd_finish: 2 words each
     bool chg_ready = false;
     // what the cell updates since the last rebuild of the derived maps can have changed: the box, in padded
     // coordinates, of the updated cells and their neighbours; whether the component labels need the full relabelling (a
@@ -415,9 +416,12 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
                     }
                 }
                 room = room && d.d_chglist.ensure((size_t)(na + nb)) == hipSuccess;
-                if (room)
-                    chg = fx::ChangeOut{d.d_chgmap.p, d.d_chglist.p, d.d_chgcnt.p, (uint32_t)(na + nb), fx::MapRange{d.bx0, d.bx1, d.by0, d.by1}};
-                else
+                constexpr uint32_t OVF_CAP = 16384;  // long walks handed on per update (2 words each); beyond it the records are streamed
+                room = room && d.d_chgovf.ensure((size_t)2 * OVF_CAP) == hipSuccess;
+                if (room) {
+                    chg = fx::ChangeOut{d.d_chgmap.p, d.d_chglist.p, d.d_chgcnt.p, (uint32_t)(na + nb), fx::MapRange{d.bx0, d.bx1, d.by0, d.by1}, d.d_chgovf.p, OVF_CAP};
+                    if (const char* e = getenv("FXJPS_JD_OVF_CAP")) chg.ovf_cap = (uint32_t)std::min(std::max(atoi(e), 0), (int)OVF_CAP);  // (test aid)
+                } else
                     (void)hipGetLastError();  // (the failed allocation's sticky error: not this update's business)
             }
             hipLaunchKernelGGL(fx::k_derive_cellinfo, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, d.stream, G, d.ci.p, sa, sb, chg);
@@ -443,7 +447,11 @@ int derive_maps(fxjps* h, DevCtx& d, bool whole = true) {
                 // direction) instead of by reading every record
                 const int walk_max = getenv("FXJPS_JD_WALK_MAX") ? std::max(1, atoi(getenv("FXJPS_JD_WALK_MAX"))) : FXJPS_JD_WALK_MAX;  // (test aid)
                 const long long nt = (long long)chg.cap * 8, nc = (long long)d.W * d.H;
-                hipLaunchKernelGGL(fx::k_jd_walk, dim3((unsigned)std::min<long long>((nt + 255) / 256, 2048)), dim3(256), 0, d.stream, G, d.jd.p, chg, dr, walk_max);
+                // (walks pay while the changed cells are few against the table: past W * H / 128 of them the records are streamed
+                // -- measured at 4096^2 over obstacle densities 0 ... 0.2, profiles/r06_map_build.txt)
+                const int div = getenv("FXJPS_JD_STREAM_DIV") ? std::max(1, atoi(getenv("FXJPS_JD_STREAM_DIV"))) : 128;  // (measurement / test aid)
+                const uint32_t stream_over = (uint32_t)std::max<long long>(nc / div, 1024);
+                hipLaunchKernelGGL(fx::k_jd_walk, dim3((unsigned)std::min<long long>((nt + 255) / 256, 2048)), dim3(256), 0, d.stream, G, d.jd.p, chg, dr, walk_max, stream_over);
                 hipLaunchKernelGGL(fx::k_jd_finish, dim3((unsigned)std::min<long long>((nc + 255) / 256, 1024)), dim3(256), 0, d.stream, G, d.jd.p, chg, dr);
             } else if (box) {
                 const long long nc = (long long)d.W * d.H;
@@ -1606,6 +1614,7 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_chgmap.release();
         d.d_chglist.release();
         d.d_chgcnt.release();
+        d.d_chgovf.release();
         d.h_len.release();
         d.h_cells.release();
         d.h_cost.release();

@@ -36,16 +36,20 @@ def check_against_fresh(p, q, cur, tag):
     return len(np.unique(ra)), len(np.unique(rb))
 
 
-@pytest.mark.parametrize("jd_mode", ["walk", "walk_max_3", "stream"])
+@pytest.mark.parametrize("jd_mode", ["walk", "walk_max_3", "walk_max_3_no_list", "stream"])
 def test_partial_rebuild_equals_fresh_upload(oracle, jd_mode, monkeypatch):
     """jd_mode: how the jump distances follow an update -- from the changed cells backwards (k_jd_walk; on the open maps
-    below walks outgrow their bound and the records are streamed after all), the same with walks of at most 3 steps (the
-    hand-over to the streaming form on every map), every record read (round 4's k_update_jd)."""
+    below walks outgrow their bound and a wavefront of k_jd_finish carries each of them on), the same with walks of at
+    most 3 steps (that hand-over on every map, nearly every walk), the same without room for a single handed-on walk (the
+    records are streamed after all), every record read (round 4's k_update_jd)."""
     import fuxi_planner_amd as fx
     from fuxi_planner_amd import synth
     from test_gpu_parity import gpu_vs_oracle
-    if jd_mode == "walk_max_3":
+    if jd_mode.startswith("walk_max_3"):
         monkeypatch.setenv("FXJPS_JD_WALK_MAX", "3")
+        monkeypatch.setenv("FXJPS_JD_STREAM_DIV", "1")  # (walk however many cells changed: by default many of them means streaming up front)
+        if jd_mode.endswith("no_list"):
+            monkeypatch.setenv("FXJPS_JD_OVF_CAP", "0")
     elif jd_mode == "stream":
         monkeypatch.setenv("FXJPS_JD_WALK", "0")
     rng = np.random.default_rng(77)
