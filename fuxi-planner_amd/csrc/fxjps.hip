@@ -224,6 +224,7 @@ struct DevCtx {
     // shard of the current batch
     int64_t q0 = 0, nq = 0;
     double kernel_ms = 0;
+    int wall_khz = 100000;  // hipDeviceAttributeWallClockRate (wall_clock64 ticks per ms)
     int64_t launches = 0, retried = 0;
     uint32_t waves_used = 0;  // resident wavefronts of the last regular-pool launch
     bool waves_short = false; // a scratch pool was granted fewer wavefronts than the batch asked for (memory budget / out of memory)
@@ -1130,7 +1131,6 @@ int plan_single(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals
     void* dp_cnt = nullptr;
     HIPCHK(h, hipHostGetDevicePointer(&dp_cnt, d.h_counters.p, 0));
     A.host_counters = (unsigned long long*)dp_cnt;
-    HIPCHK(h, hipEventRecord(d.ev0, d.stream));
     {
         using KFn = void (*)(SearchArgs);
         static const KFn kfn[2][2] = {{fx::k_search<1, false, false>, fx::k_search<1, false, true>},
@@ -1138,11 +1138,13 @@ int plan_single(fxjps* h, DevCtx& d, const int32_t* starts, const int32_t* goals
         hipLaunchKernelGGL(kfn[hchoice == 1 ? 0 : 1][c.direct_ly > 0 ? 1 : 0], dim3(1), dim3(fx::WAVE * fx::WPB), 0, d.stream, A);
         HIPCHK(h, hipGetLastError());
     }
-    HIPCHK(h, hipEventRecord(d.ev1, d.stream));
     HIPCHK(h, hipStreamSynchronize(d.stream));
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, d.ev0, d.ev1));
-    d.kernel_ms = ms;
+    // (the kernel's time by the device's constant-rate clock, read by the one wavefront at its first and last instruction: two
+    // event records and hipEventElapsedTime were three more runtime calls on a 250 us call)
+    d.kernel_ms = (double)(d.h_counters.p[63] - d.h_counters.p[62]) / (double)d.wall_khz;
+    DBG("single call: kernel %.1f us, %llu pops, shader clock %.0f MHz", d.kernel_ms * 1e3, (unsigned long long)d.h_counters.p[0],
+        d.kernel_ms > 0 ? (double)(d.h_counters.p[61] - d.h_counters.p[60]) / (d.kernel_ms * 1e3) : 0.0);
+    d.h_counters.p[60] = d.h_counters.p[61] = d.h_counters.p[62] = d.h_counters.p[63] = 0ull;
     d.launches = 1;
     const int32_t n = d.h_len.p[0];
     if (n <= fx::QI_TABLE_FULL) return 1;  // outgrew the regular scratch (or the watchdog): the batch path has the large pool
@@ -1459,6 +1461,11 @@ int fxjps_create(int backend, const int* device_ids, int n_dev, fxjps_t** out) {
         }
         d.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         d.mem_total = prop.totalGlobalMem;
+        {
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, d.dev) == hipSuccess && khz > 0) d.wall_khz = khz;
+            (void)hipGetLastError();
+        }
     }
     for (auto& a : h->devs) {
         a.share = 0;

@@ -16,7 +16,7 @@ from ._lib import FxjpsError
 def as_occ(matrix):
     """The reference treats a cell as an obstacle iff it compares equal to 1
     (jps1.py:20-29); 100, 0.5, -1 ... are free."""
-    return np.ascontiguousarray(np.asarray(matrix) == 1, dtype=np.uint8)
+    return np.ascontiguousarray(np.asarray(matrix) == 1).view(np.uint8)  # (bool -> uint8 is a view: no second pass over the cells)
 
 
 class Planner(object):

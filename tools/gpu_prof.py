@@ -14,11 +14,24 @@ p = fx.Planner([0])
 L = _lib.load()
 L.fxjps_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 occ = synth.synth_grid(W, W, 1 if W == 1024 else 2, 0.20)
+C1Q = None
+if os.environ.get("FX_C1"):  # BASELINE config 1: the reference map in its 256 x 256 canvas, query FX_C1 (0 .. 2) of SURVEY 8(c) alone
+    import json
+    z = np.load(os.path.join(ROOT, "tests", "golden", "maps_png.npz"))
+    recs = json.load(open(os.path.join(ROOT, "tests", "golden", "maps_png.json")))
+    nm = "-16.20-11.40_out.png"
+    w_, h_ = [r for r in recs if r["map"] == nm and "canvas" not in r][0]["shape"]
+    occ = np.zeros((256, 256), np.uint8)
+    occ[:w_, :h_] = np.unpackbits(z[nm])[:w_ * h_].reshape(w_, h_)
+    C1Q = [((0, 0), (146, 111)), ((2, 2), (140, 100)), ((5, 100), (140, 5))][int(os.environ["FX_C1"])]
 p.set_grid_occ(occ)
 names = ["take batch", "c:wait+probe_eval", "c:write+push+merge", "x:dirs+issue", "x:eval+diag", "x:more+bcast", "c:math+nvalid", "c:hazard", "R/M/far refills", "looptop"]
 for nq in nqs:
     s, g = synth.synth_queries(occ, 1 if W == 1024 else 2, nq)
-    if os.environ.get("FX_QIDS"):  # only these queries of the stream (e.g. one heavy query on an idle chip)
+    if C1Q is not None:
+        s, g = np.array([C1Q[0]], np.int32), np.array([C1Q[1]], np.int32)
+        nq = 1
+    if os.environ.get("FX_QIDS") and C1Q is None:  # only these queries of the stream (e.g. one heavy query on an idle chip)
         ids = [int(v) for v in os.environ["FX_QIDS"].split(",")]
         s, g = s[ids], g[ids]
         nq = len(ids)
