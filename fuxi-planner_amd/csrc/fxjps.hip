@@ -189,6 +189,10 @@ struct DevCtx {
     DBuf<double> d_wp_in, d_wp_out;
     DBuf<int32_t> d_wp_eo, d_wp_nkept, d_wp_kept, d_wp_cells, d_wp_len;
     DBuf<long long> d_wp_off;
+    // ... the st rule (fxjps_waypoint_st_batch): per-query inputs / outputs, and the host libm's atan2 of integer pairs
+    DBuf<int32_t> d_wp_ms, d_wp_pdim, d_wp_dim;
+    DBuf<double> d_wp_prev, d_wp_ang, d_atab;
+    int atab_a = -1, atab_b = -1;  // d_atab holds atan2(a, b) for a in [0, atab_a], b in [-atab_b, atab_b]
     DBuf<int32_t> d_upd_xy;
     DBuf<uint8_t> d_upd_chg;
     DBuf<int> d_owner;        // [W][H], -1 at rest: which entry of an update list decides a cell it names several times
@@ -1377,6 +1381,53 @@ void drain_all(fxjps* h) {
     h->err = keep;
 }
 
+// ---- waypoint selection over a batch: where the paths are.  The caller's CSR (device 0 takes all of them), or the last
+// batch's, resident shard by shard on the devices that planned them.
+struct WpPart {
+    DevCtx* d;
+    int64_t q0, n;
+    const long long* d_off;
+    const int32_t *d_cells, *d_len;
+    long long total;
+};
+int wp_gather_parts(fxjps* h, int64_t nq, const int64_t* offsets, const int32_t* cells_xy, bool nonneg, std::vector<WpPart>& parts,
+                    std::vector<int64_t>& kept_at, int64_t& kept_base) {
+    kept_base = 0;
+    if (cells_xy) {
+        for (int64_t q = 0; q < nq; q++)
+            if (offsets[q + 1] < offsets[q]) return fail(h, FXJPS_E_ARG, "offsets must ascend");
+        if (offsets[0] != 0) return fail(h, FXJPS_E_ARG, "offsets[0] must be 0");
+        if (nonneg)
+            for (int64_t i = 0; i < 2 * offsets[nq]; i++)
+                if (cells_xy[i] < 0) return fail(h, FXJPS_E_ARG, "negative cell");
+        DevCtx& d = h->devs[0];
+        HIPCHK(h, hipSetDevice(d.dev));
+        const long long total = offsets[nq];
+        HIPCHK(h, d.d_wp_off.ensure((size_t)nq + 1));
+        HIPCHK(h, d.d_wp_len.ensure((size_t)nq));
+        HIPCHK(h, d.d_wp_cells.ensure((size_t)std::max<long long>(total, 1) * 2));
+        std::vector<int32_t> len((size_t)nq);
+        for (int64_t q = 0; q < nq; q++) len[(size_t)q] = (int32_t)std::min<int64_t>(offsets[q + 1] - offsets[q], 0x7FFFFFFF);
+        static_assert(sizeof(long long) == sizeof(int64_t), "offsets are copied as they are");
+        HIPCHK(h, hipMemcpyAsync(d.d_wp_off.p, offsets, ((size_t)nq + 1) * sizeof(long long), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipMemcpyAsync(d.d_wp_len.p, len.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        if (total > 0) HIPCHK(h, hipMemcpyAsync(d.d_wp_cells.p, cells_xy, (size_t)total * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(h, hipStreamSynchronize(d.stream));  // (`len` is pageable host memory)
+        parts.push_back(WpPart{&d, 0, nq, d.d_wp_off.p, d.d_wp_cells.p, d.d_wp_len.p, total});
+        kept_at.push_back(0);
+        kept_base = total;
+    } else {
+        for (auto& d : h->devs) {
+            if (d.nq == 0) continue;
+            const long long total = d.h_offsets.p[d.nq];
+            parts.push_back(WpPart{&d, d.q0, d.nq, d.d_offsets.p, d.d_cells.p, d.d_len.p, total});
+            kept_at.push_back(kept_base);
+            kept_base += total;
+        }
+    }
+    return FXJPS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1615,6 +1666,12 @@ void fxjps_destroy(fxjps_t* h) {
         d.d_wp_cells.release();
         d.d_wp_len.release();
         d.d_wp_off.release();
+        d.d_wp_ms.release();
+        d.d_wp_pdim.release();
+        d.d_wp_dim.release();
+        d.d_wp_prev.release();
+        d.d_wp_ang.release();
+        d.d_atab.release();
         d.d_upd_xy.release();
         d.d_upd_chg.release();
         d.d_owner.release();
@@ -2304,46 +2361,12 @@ int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, co
     }
     if (nq == 0) return FXJPS_OK;
     // the paths: the caller's CSR (device 0 takes all of them), or the last batch's, resident shard by shard
-    struct Part {
-        DevCtx* d;
-        int64_t q0, n;
-        const long long* d_off;
-        const int32_t *d_cells, *d_len;
-        long long total;
-    };
-    std::vector<Part> parts;
+    std::vector<WpPart> parts;
     int64_t kept_base = 0;
     std::vector<int64_t> kept_at;
-    if (cells_xy) {
-        for (int64_t q = 0; q < nq; q++)
-            if (offsets[q + 1] < offsets[q]) return fail(h, FXJPS_E_ARG, "offsets must ascend");
-        if (offsets[0] != 0) return fail(h, FXJPS_E_ARG, "offsets[0] must be 0");
-        for (int64_t i = 0; i < 2 * offsets[nq]; i++)
-            if (cells_xy[i] < 0) return fail(h, FXJPS_E_ARG, "negative cell");
-        DevCtx& d = h->devs[0];
-        HIPCHK(h, hipSetDevice(d.dev));
-        const long long total = offsets[nq];
-        HIPCHK(h, d.d_wp_off.ensure((size_t)nq + 1));
-        HIPCHK(h, d.d_wp_len.ensure((size_t)nq));
-        HIPCHK(h, d.d_wp_cells.ensure((size_t)std::max<long long>(total, 1) * 2));
-        std::vector<int32_t> len((size_t)nq);
-        for (int64_t q = 0; q < nq; q++) len[(size_t)q] = (int32_t)std::min<int64_t>(offsets[q + 1] - offsets[q], 0x7FFFFFFF);
-        static_assert(sizeof(long long) == sizeof(int64_t), "offsets are copied as they are");
-        HIPCHK(h, hipMemcpyAsync(d.d_wp_off.p, offsets, ((size_t)nq + 1) * sizeof(long long), hipMemcpyHostToDevice, d.stream));
-        HIPCHK(h, hipMemcpyAsync(d.d_wp_len.p, len.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-        if (total > 0) HIPCHK(h, hipMemcpyAsync(d.d_wp_cells.p, cells_xy, (size_t)total * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
-        HIPCHK(h, hipStreamSynchronize(d.stream));  // (`len` is pageable host memory)
-        parts.push_back(Part{&d, 0, nq, d.d_wp_off.p, d.d_wp_cells.p, d.d_wp_len.p, total});
-        kept_at.push_back(0);
-        kept_base = total;
-    } else {
-        for (auto& d : h->devs) {
-            if (d.nq == 0) continue;
-            const long long total = d.h_offsets.p[d.nq];
-            parts.push_back(Part{&d, d.q0, d.nq, d.d_offsets.p, d.d_cells.p, d.d_len.p, total});
-            kept_at.push_back(kept_base);
-            kept_base += total;
-        }
+    {
+        int rc = wp_gather_parts(h, nq, offsets, cells_xy, true, parts, kept_at, kept_base);
+        if (rc) return rc;
     }
     if (out_kept_cells && kept_capacity < kept_base)
         return fail(h, FXJPS_E_ARG, "out_kept_cells holds %lld pairs, the paths have %lld", (long long)kept_capacity, (long long)kept_base);
@@ -2409,6 +2432,140 @@ int fxjps_waypoint_st_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, cons
     if ((cells_xy != nullptr) != (offsets != nullptr)) return fail(h, FXJPS_E_ARG, "offsets and cells_xy go together");
     if ((prev_wp != nullptr) != (prev_dim != nullptr)) return fail(h, FXJPS_E_ARG, "prev_wp and prev_dim go together");
     if (!cells_xy && nq != h->last_nq) return fail(h, FXJPS_E_ARG, "the last batch had %lld queries, not %lld", (long long)h->last_nq, (long long)nq);
+    if (nq == 0) return FXJPS_OK;
+    // ---- on the device (round 6): one wavefront per path, the angles out of a table of the HOST's atan2 over the integer
+    // pairs this batch can ask for.  The table is filled once per range (threads of this call) and stays on the device.
+    if (!(getenv("FXJPS_WAYPOINT_ST_HOST") && atoi(getenv("FXJPS_WAYPOINT_ST_HOST")) != 0)) {  // (1: the host form, test / measurement aid)
+        if (!cells_xy && h->last_on_host) {  // (a single call's path is in the pinned host buffers: handed over like a caller's CSR)
+            static_assert(sizeof(long long) == sizeof(int64_t), "offsets are handed over as they are");
+            offsets = reinterpret_cast<const int64_t*>(h->devs[0].h_offsets.p);
+            cells_xy = h->devs[0].h_cells.p;
+        }
+        // the range of (cell + 1 - map_start) over the batch
+        long long cx0 = 0, cx1 = 0, cy0 = 0, cy1 = 0;
+        if (cells_xy) {
+            if (offsets[nq] > 0) {
+                cx0 = cx1 = cells_xy[0];
+                cy0 = cy1 = cells_xy[1];
+            }
+            for (int64_t i = 0; i < offsets[nq]; i++) {
+                cx0 = std::min<long long>(cx0, cells_xy[2 * i]);
+                cx1 = std::max<long long>(cx1, cells_xy[2 * i]);
+                cy0 = std::min<long long>(cy0, cells_xy[2 * i + 1]);
+                cy1 = std::max<long long>(cy1, cells_xy[2 * i + 1]);
+            }
+        } else {  // (resident paths lie on the grid)
+            cx1 = h->devs[0].W - 1;
+            cy1 = h->devs[0].H - 1;
+        }
+        long long am = 0, bm = 0;
+        for (int64_t q = 0; q < nq; q++) {
+            const long long mx = map_start[2 * q], my = map_start[2 * q + 1];
+            am = std::max(am, std::max(std::llabs(cx0 + 1 - mx), std::llabs(cx1 + 1 - mx)));
+            bm = std::max(bm, std::max(std::llabs(cy0 + 1 - my), std::llabs(cy1 + 1 - my)));
+        }
+        constexpr long long ATAB_MAX = 1ll << 27;  // entries (1 GiB): a map_start far off the grid takes the host form below
+        if ((am + 1) * (2 * bm + 1) <= ATAB_MAX && am < (1ll << 30) && bm < (1ll << 30)) {
+            std::vector<WpPart> parts;
+            std::vector<int64_t> kept_at;
+            int64_t kept_base = 0;
+            int rc = wp_gather_parts(h, nq, offsets, cells_xy, false, parts, kept_at, kept_base);
+            if (rc) return rc;
+            // the table: grown to the largest range seen on each device, filled by the host's libm
+            std::vector<double> tab;
+            int ta = -1, tb = -1;
+            for (auto& P : parts) {
+                DevCtx& d = *P.d;
+                if (d.atab_a >= (int)am && d.atab_b >= (int)bm) continue;
+                const int na = std::max<int>((int)am, d.atab_a), nb = std::max<int>((int)bm, d.atab_b);
+                if ((long long)(na + 1) * (2ll * nb + 1) > ATAB_MAX) {  // (the union of two ranges may not fit: start over with this one)
+                    d.atab_a = d.atab_b = -1;
+                }
+                const int wa = d.atab_a < 0 ? (int)am : na, wb = d.atab_b < 0 ? (int)bm : nb;
+                if (ta != wa || tb != wb) {
+                    ta = wa;
+                    tb = wb;
+                    const size_t row = (size_t)(2 * tb + 1);
+                    tab.resize((size_t)(ta + 1) * row);
+                    int nt = std::max(1, std::min<int>(nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency(), 64));
+                    nt = (int)std::min<long long>(nt, std::max<long long>((long long)tab.size() >> 16, 1));
+                    double* T = tab.data();
+                    (void)run_side_by_side((size_t)nt, [&](size_t t) {
+                        for (long long a = (long long)(ta + 1) * (long long)t / nt; a < (long long)(ta + 1) * (long long)(t + 1) / nt; a++)
+                            for (long long b = -tb; b <= tb; b++) T[(size_t)a * row + (size_t)(b + tb)] = std::atan2((double)a, (double)b);
+                        return 0;
+                    });
+                }
+                HIPCHK(h, hipSetDevice(d.dev));
+                HIPCHK(h, d.d_atab.ensure(tab.size()));
+                HIPCHK(h, hipMemcpyAsync(d.d_atab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, d.stream));
+                HIPCHK(h, hipStreamSynchronize(d.stream));  // (`tab` is pageable and dies with this call)
+                d.atab_a = ta;
+                d.atab_b = tb;
+            }
+            rc = [&]() -> int {
+                for (auto& P : parts) {  // queue every device, then collect
+                    DevCtx& d = *P.d;
+                    HIPCHK(h, hipSetDevice(d.dev));
+                    const size_t n = (size_t)P.n;
+                    HIPCHK(h, d.d_wp_in.ensure(n * 6));
+                    HIPCHK(h, d.d_wp_out.ensure(n * 6));
+                    HIPCHK(h, d.d_wp_eo.ensure(n));
+                    HIPCHK(h, d.d_wp_ms.ensure(n * 2));
+                    HIPCHK(h, d.d_wp_prev.ensure(n * 3));
+                    HIPCHK(h, d.d_wp_pdim.ensure(n));
+                    HIPCHK(h, d.d_wp_dim.ensure(n));
+                    HIPCHK(h, d.d_wp_ang.ensure(n));
+                    HIPCHK(h, hipMemcpyAsync(d.d_wp_in.p, pos + 3 * P.q0, n * 3 * sizeof(double), hipMemcpyHostToDevice, d.stream));
+                    HIPCHK(h, hipMemcpyAsync(d.d_wp_in.p + n * 3, goal + 3 * P.q0, n * 3 * sizeof(double), hipMemcpyHostToDevice, d.stream));
+                    HIPCHK(h, hipMemcpyAsync(d.d_wp_ms.p, map_start + 2 * P.q0, n * 2 * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+                    if (end_occu) HIPCHK(h, hipMemcpyAsync(d.d_wp_eo.p, end_occu + P.q0, n * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+                    if (prev_wp) {
+                        HIPCHK(h, hipMemcpyAsync(d.d_wp_prev.p, prev_wp + 3 * P.q0, n * 3 * sizeof(double), hipMemcpyHostToDevice, d.stream));
+                        HIPCHK(h, hipMemcpyAsync(d.d_wp_pdim.p, prev_dim + P.q0, n * sizeof(int32_t), hipMemcpyHostToDevice, d.stream));
+                    }
+                    fx::WaypointStArgs A;
+                    A.cells = P.d_cells;
+                    A.offsets = P.d_off;
+                    A.len = P.d_len;
+                    A.nq = (long long)P.n;
+                    A.map_start = d.d_wp_ms.p;
+                    A.reso = reso;
+                    A.ox = origin[0];
+                    A.oy = origin[1];
+                    A.pos = d.d_wp_in.p;
+                    A.goal = d.d_wp_in.p + n * 3;
+                    A.end_occu = end_occu ? d.d_wp_eo.p : nullptr;
+                    A.dis_wp_tre = dis_wp_tre;
+                    A.ang_wp_tre = ang_wp_tre;
+                    A.prev_wp = prev_wp ? d.d_wp_prev.p : nullptr;
+                    A.prev_dim = prev_wp ? d.d_wp_pdim.p : nullptr;
+                    A.atab = d.d_atab.p;
+                    A.amax = d.atab_a;
+                    A.bmax = d.atab_b;
+                    A.out_wp = d.d_wp_out.p;
+                    A.out_dim = d.d_wp_dim.p;
+                    A.out_goal = d.d_wp_out.p + n * 3;
+                    A.out_ang = d.d_wp_ang.p;
+                    hipLaunchKernelGGL(fx::k_waypoint_st, dim3((unsigned)((P.n + 3) / 4)), dim3(256), 0, d.stream, A);
+                    HIPCHK(h, hipGetLastError());
+                    HIPCHK(h, hipMemcpyAsync(out_wp + 3 * P.q0, d.d_wp_out.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+                    HIPCHK(h, hipMemcpyAsync(out_goal + 3 * P.q0, d.d_wp_out.p + n * 3, n * 3 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+                    HIPCHK(h, hipMemcpyAsync(out_dim + P.q0, d.d_wp_dim.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, d.stream));
+                    HIPCHK(h, hipMemcpyAsync(out_ang_wp + P.q0, d.d_wp_ang.p, n * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+                }
+                return FXJPS_OK;
+            }();
+            if (rc) {  // copies of the devices in front of the failing one are still queued on the caller's buffers
+                drain_all(h);
+                return rc;
+            }
+            for (auto& P : parts)
+                if (hipSetDevice(P.d->dev) != hipSuccess || hipStreamSynchronize(P.d->stream) != hipSuccess) rc = fail(h, FXJPS_E_HIP, "waypoint kernel failed");
+            return rc;
+        }
+    }
+    // ---- on host threads: a map_start so far off the grid that the table of angles would not fit (or FXJPS_WAYPOINT_ST_HOST=1)
     // path q: its cells and their number (the last batch's paths are in the handle's pinned host buffers, shard by shard)
     auto path_of = [&](int64_t q, const int32_t** c) -> int64_t {
         if (cells_xy) {

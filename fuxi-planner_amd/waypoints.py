@@ -130,7 +130,8 @@ def select_ccst_batch(planner, nq, map_reso, map_o, pos, global_goal, end_occu=N
 
 def select_st_batch(planner, nq, map_start, map_reso, map_o, pos, global_goal, end_occu=None, prev_wp=None, prev_dim=None, paths=None,
                     dis_wp_tre=2.0, ang_wp_tre=math.pi / 4, nthreads=0):
-    """global_planner_st.py:292-327 for every path of a batch, on host threads (fxjps_waypoint_st_batch).
+    """global_planner_st.py:292-327 for every path of a batch, one wavefront per path on the device (fxjps_waypoint_st_batch;
+    the angles come out of a table of the host's own atan2, filled by `nthreads` host threads once per range of map_start).
     -> (wp float64[nq, 3], dim int32[nq] (2 or 3 valid components), global_goal float64[nq, 3], ang_wp float64[nq])"""
     nq, off, cells = _batch_paths(planner, paths, int(nq))
     o = _vec(map_o, 2)

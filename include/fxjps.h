@@ -357,9 +357,14 @@ int fxjps_waypoint_ccst(const int32_t* cells, int32_t n, const uint8_t* occ, int
  * remaining points, out_kept_cells (optional, kept_capacity pairs >= offsets[nq]) the remaining cells of path q at
  * offsets[q] (the offsets of the paths themselves).
  *
- * fxjps_waypoint_st_batch stays on the host (its decisions hang on libm's atan2, as CPython's do) but takes the whole
- * batch: nthreads host threads (0: all cores) walk the paths; map_start is nq x 2, prev_wp nq x 3 with prev_dim[q] in
- * {0: None, 2, 3} (both NULL: no previous waypoints), out_dim / out_ang_wp nq values. */
+ * fxjps_waypoint_st_batch runs on the device too (version 600+): one wavefront per path, the rule's loop as a comparison
+ * of neighbouring lanes.  Its decisions -- and the angle it returns -- hang on libm's atan2 of integer pairs
+ * (cell + 1 - map_start), as CPython's math.atan2 does: the device looks them up in a table that this call fills with
+ * the HOST's atan2 (nthreads host threads, 0: all cores) for the range of pairs the batch can ask for, once per range,
+ * and keeps on the device (17 MB for a 1024 x 1024 grid).  A map_start so far off the grid that the table would exceed
+ * 2^27 entries makes the call walk the batch on nthreads host threads instead.  map_start is nq x 2, prev_wp nq x 3
+ * with prev_dim[q] in {0: None, 2, 3} (both NULL: no previous waypoints), out_dim / out_ang_wp nq values; results
+ * bit-identical to fxjps_waypoint_st path by path. */
 int fxjps_waypoint_ccst_batch(fxjps_t* h, int64_t nq, const int64_t* offsets, const int32_t* cells_xy, double reso, const double* origin,
                               const double* pos, const double* goal, const int32_t* end_occu, double* out_wp, double* out_goal,
                               int32_t* out_n_kept, int32_t* out_kept_cells, int64_t kept_capacity);

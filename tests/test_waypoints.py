@@ -85,3 +85,21 @@ def test_edge_cases():
         waypoints.select_ccst([], occ, 1.0, (0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
     with pytest.raises(fx.FxjpsError):
         waypoints.select_ccst([(-1, 2)], occ, 1.0, (0.0, 0.0), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+
+
+def test_host_atan2_is_odd_in_its_first_argument():
+    """The device form of the st rule (k_waypoint_st) looks atan2(dx, dy) of integer pairs up in a table the host fills for
+    dx >= 0 only and negates for dx < 0: exact iff libm's atan2(-a, b) == -atan2(a, b) bit for bit.  Checked here on a dense
+    range and on random large pairs (math.atan2 is the libm the reference's math.atan2 calls)."""
+    import math
+    import random
+    import struct
+    bits = lambda v: struct.pack("<d", v)
+    for a in range(1, 400):
+        for b in range(-400, 401):
+            assert bits(math.atan2(-a, b)) == bits(-math.atan2(a, b)), (a, b)
+    rnd = random.Random(5)
+    for _ in range(200000):
+        a, b = rnd.randint(1, 8192), rnd.randint(-8192, 8192)
+        assert bits(math.atan2(-a, b)) == bits(-math.atan2(a, b)), (a, b)
+    assert math.atan2(0, -3) == math.pi and math.atan2(0, 3) == 0.0 and math.atan2(0, 0) == 0.0

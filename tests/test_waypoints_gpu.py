@@ -139,3 +139,73 @@ def test_batch_edges(planner):
                 continue
             w1, k1, g1 = waypoints.select_ccst(p, occ, 0.5, (1.0, -2.0), pos[q], goal[q], int(eo[q]), return_goal=True)
             assert np.array_equal(kept[off[q]:off[q] + nk[q]], k1) and wp[q].tobytes() == w1.tobytes() and gout[q].tobytes() == g1.tobytes(), q
+
+
+def test_st_rule_on_the_device_equals_the_host_form(planner, monkeypatch):
+    """fxjps_waypoint_st_batch runs on the device (round 6: one wavefront per path, the angles out of a table the host's own
+    atan2 filled).  Against the threaded host form (FXJPS_WAYPOINT_ST_HOST=1) on every path of a planned batch with last
+    tick's waypoints of 0 / 2 / 3 components; against the one-path function on long paths built so that the loop ends at
+    the 1st ... 300th point (the kernel takes 64 points per step and carries the angle over); with a map_start so far off
+    the grid that the table would not fit (the call then takes the host form by itself); on a handle with three contexts."""
+    import fuxi_planner_amd as fx
+    from fuxi_planner_amd import synth, waypoints
+    occ = synth.synth_grid(640, 512, 3, 0.2)
+    nq = 6000
+    s, g = synth.synth_queries(occ, 3, nq)
+    planner.set_grid_occ(occ)
+    off, cells, cost, st = planner.plan_batch(s, g, 2, 1024)
+    rng = np.random.default_rng(3)
+    reso, origin = 0.25, np.array([1.5, -40.0])
+    pos = np.c_[(s[:, 0] + 1) * reso + origin[0] + rng.normal(0, 0.6, nq), (s[:, 1] + 1) * reso + origin[1] + rng.normal(0, 0.6, nq), rng.choice([0.0, 1.0], nq)]
+    goal = np.c_[(g[:, 0] + 1) * reso + origin[0], (g[:, 1] + 1) * reso + origin[1], np.full(nq, 1.5)]
+    eo = (rng.random(nq) < 0.1).astype(np.int32)
+    ms = s + 1 + rng.integers(-3, 4, (nq, 2))
+    prev = rng.uniform(-5, 200, (nq, 3))
+    pdim = rng.choice([0, 2, 3], nq).astype(np.int32)
+    for tre in ((2.0, np.pi / 4), (0.5, 0.05)):
+        dev = waypoints.select_st_batch(planner, nq, ms, reso, origin, pos, goal, eo, prev, pdim, dis_wp_tre=tre[0], ang_wp_tre=tre[1])
+        dev2 = waypoints.select_st_batch(planner, nq, ms, reso, origin, pos, goal, eo, prev, pdim, paths=(off, cells), dis_wp_tre=tre[0], ang_wp_tre=tre[1])
+        monkeypatch.setenv("FXJPS_WAYPOINT_ST_HOST", "1")
+        host = waypoints.select_st_batch(planner, nq, ms, reso, origin, pos, goal, eo, prev, pdim, dis_wp_tre=tre[0], ang_wp_tre=tre[1])
+        monkeypatch.delenv("FXJPS_WAYPOINT_ST_HOST")
+        for x, y, z in zip(dev, dev2, host):
+            assert x.tobytes() == z.tobytes() and y.tobytes() == z.tobytes()
+        assert len(set(dev[1].tolist())) == 2 and (dev[3] > 0).sum() > nq // 2  # (both kinds of waypoint, angles that are not trivial)
+    # long paths: the angle to the goal's bearing grows point by point and turns back at point `turn`
+    paths, mss = [], []
+    for n, turn in ((300, 299), (300, 64), (300, 65), (300, 63), (300, 128), (300, 129), (129, 128), (65, 64), (64, 63), (2, 1), (1, 0), (200, 1), (300, 250)):
+        R = 2500.0
+        phi = np.linspace(0.0, 1.1, n)
+        pts = np.stack([np.rint(R * np.sin(phi)), np.rint(R * np.cos(phi))], 1).astype(np.int32) + 7
+        if 0 < turn < n - 1:  # (an angle no larger than the one in front of it)
+            pts[turn] = pts[turn - 1] + np.array([0, 3] if turn > 1 else [0, 5], np.int32)
+        pts[-1] = (7, 7 + 2400)  # the goal straight ahead
+        paths.append(pts)
+        mss.append((8, 8))
+    off2 = np.zeros(len(paths) + 1, dtype=np.int64)
+    off2[1:] = np.cumsum([len(p) for p in paths])
+    cells2 = np.concatenate(paths).astype(np.int32)
+    n2 = len(paths)
+    pos2 = np.c_[rng.uniform(0, 10, n2), rng.uniform(0, 10, n2), np.zeros(n2)]
+    goal2 = np.c_[rng.uniform(0, 400, n2), rng.uniform(0, 400, n2), np.ones(n2)]
+    got = waypoints.select_st_batch(planner, n2, np.array(mss), 0.1, (0.0, 0.0), pos2, goal2, paths=(off2, cells2), dis_wp_tre=0.0, ang_wp_tre=0.0)
+    kinds = set()
+    for q, p in enumerate(paths):
+        w1, g1, a1 = waypoints.select_st(p, mss[q], 0.1, (0.0, 0.0), pos2[q], goal2[q], 0, dis_wp_tre=0.0, ang_wp_tre=0.0)
+        assert got[0][q, :got[1][q]].tobytes() == w1.tobytes() and got[2][q].tobytes() == g1.tobytes() and got[3][q] == a1, (q, got[3][q], a1)
+        kinds.add(int(got[1][q]))
+    assert kinds == {2, 3}
+    # a map_start far off the grid: the table of angles would not fit, the host form answers
+    far = np.tile(np.array([[3000000, -2000000]], np.int32), (n2, 1))
+    got = waypoints.select_st_batch(planner, n2, far, 0.1, (0.0, 0.0), pos2, goal2, paths=(off2, cells2))
+    for q, p in enumerate(paths):
+        w1, g1, a1 = waypoints.select_st(p, far[q], 0.1, (0.0, 0.0), pos2[q], goal2[q], 0)
+        assert got[0][q, :got[1][q]].tobytes() == w1.tobytes() and got[3][q] == a1, q
+    # several contexts: each shard's paths stay where they were planned
+    with fx.Planner([0, 0, 0]) as p3:
+        p3.set_grid_occ(occ)
+        res = p3.plan_batch(s[:901], g[:901], 2, 1024)
+        a = waypoints.select_st_batch(p3, 901, ms[:901], reso, origin, pos[:901], goal[:901], eo[:901], prev[:901], pdim[:901])
+        b = waypoints.select_st_batch(planner, 901, ms[:901], reso, origin, pos[:901], goal[:901], eo[:901], prev[:901], pdim[:901],
+                                      paths=(res[0], res[1]))
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
