@@ -91,11 +91,19 @@ def main():
                     w1, k1 = waypoints.select_ccst(cells[off[k]:off[k + 1]], cur, 1.0, (0.0, 0.0), pos[k], goal[k])
                     if wp[k].tobytes() != w1.tobytes() or nk[k] != len(k1):
                         good = False; print("WAYPOINT MISMATCH", k, flush=True); break
+                # ... and the st rule (device kernel, angles from the table of the host's atan2) against the one-path host function
+                ms = s + 1 + rng.integers(-2, 3, s.shape)
+                pw = rng.uniform(-5, 50, (n, 3)); pd = rng.choice([0, 2, 3], n).astype(np.int32)
+                wps, dims, gs, angs = waypoints.select_st_batch(p, n, ms, 0.5, (1.0, -1.0), pos, goal, None, pw, pd)
+                for k in np.flatnonzero(st > 0)[:40]:
+                    w1, g1, a1 = waypoints.select_st(cells[off[k]:off[k + 1]], ms[k], 0.5, (1.0, -1.0), pos[k], goal[k], 0, None if pd[k] == 0 else pw[k, :pd[k]])
+                    if wps[k, :dims[k]].tobytes() != w1.tobytes() or angs[k] != a1 or gs[k].tobytes() != g1.tobytes():
+                        good = False; print("ST WAYPOINT MISMATCH", k, flush=True); break
             if good and step % 4 == 0:   # derived maps against a fresh upload
                 q.set_grid_occ(cur)
                 a, b = p.debug_maps(), q.debug_maps()
                 nmapcmp += 1
-                for name in ("nb8", "bm", "ci"):
+                for name in ("nb8", "bm", "ci", "dbm", "jd"):
                     if not np.array_equal(a[name], b[name]):
                         good = False; print("MAP MISMATCH", name, flush=True)
                 fr = np.flatnonzero(cur.ravel() == 0)
